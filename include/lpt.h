@@ -1,0 +1,327 @@
+/*
+ * lpt.h — C ABI of the MI355X-native path-tracing core that sits behind
+ * Loupiote's `crates/lib` API (crate `loupiote-core`).
+ *
+ * The reference has no FFI layer: its public Rust API *is* the boundary
+ * (reference crates/lib/src/lib.rs:1-11).  Every entry point below replaces one
+ * public Rust item; the citation after "replaces:" names it (paths relative to
+ * the reference root).  A Rust shim that keeps the `Renderer/Scene/SceneGPU/
+ * ProbeGPU/Device/loaders` signatures and forwards to these symbols is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an `int` status (LPT_OK == 0); nothing unwinds
+ *     across the boundary.  `lpt_last_error()` gives a thread-local message.
+ *   - `create/upload` return a handle the caller destroys; input pointers are
+ *     borrowed for the duration of the call only (the reference's
+ *     `new_storage_with_data` / `write_texture` copy semantics,
+ *     crates/lib/src/scene.rs:134-146, crates/lib/src/renderer.rs:646-660).
+ *   - handles are not thread-safe; one caller thread per lpt_device (the
+ *     reference drives everything from the winit thread,
+ *     crates/standalone/src/app.rs:259-344).
+ *   - matrices are 16 floats, column-major (glam::Mat4::to_cols_array()).
+ *   - plain pointers and sizes only; no torch / HIP types in any signature.
+ */
+#ifndef LPT_H
+#define LPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPT_ABI_VERSION 1u
+
+/* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
+#define LPT_INVALID_INDEX 0xFFFFFFFFu
+
+/* ---- status codes ---------------------------------------------------------
+ * replaces: enum Error { FileNotFound, TextureToBufferReadFail, AccelBuild }
+ * (crates/lib/src/errors.rs:2-6) plus the conditions the reference panics on. */
+enum {
+    LPT_OK = 0,
+    LPT_ERR_FILE_NOT_FOUND = 1, /* Error::FileNotFound(String)          */
+    LPT_ERR_READBACK = 2,       /* Error::TextureToBufferReadFail       */
+    LPT_ERR_ACCEL_BUILD = 3,    /* Error::AccelBuild(String)            */
+    LPT_ERR_HIP = 4,            /* a HIP runtime call failed / no GPU   */
+    LPT_ERR_RCCL = 5,           /* reserved for the collective path     */
+    LPT_ERR_INVALID_ARG = 6
+};
+
+const char *lpt_last_error(void);
+/* String form of a status, same text as `impl From<Error> for String`
+ * (crates/lib/src/errors.rs:8-20) for the three reference variants. */
+const char *lpt_status_string(int status);
+uint32_t lpt_abi_version(void);
+
+/* ---- plain-data structs ---------------------------------------------------- */
+
+/* replaces: albedo_rtx::uniforms::Material — exactly the five fields the
+ * reference writes (crates/lib/src/loaders/gltf.rs:113-126,
+ * crates/lib/src/loaders/binary.rs:63-69).  32 bytes. */
+typedef struct lpt_material {
+    float color[4];          /* baseColorFactor                        */
+    float roughness;         /* roughnessFactor                        */
+    float reflectivity;      /* metallicFactor                         */
+    uint32_t albedo_texture; /* image index or LPT_INVALID_INDEX       */
+    uint32_t mra_texture;    /* image index or LPT_INVALID_INDEX       */
+} lpt_material;
+
+/* replaces: albedo_rtx::uniforms::Vertex { position:[f32;4], normal:[f32;4] }
+ * (crates/lib/src/loaders/binary.rs:20-28).  uv rides in the two .w lanes. */
+typedef struct lpt_vertex {
+    float position[4]; /* x y z, u */
+    float normal[4];   /* x y z, v */
+} lpt_vertex;
+
+/* replaces: albedo_rtx::uniforms::Light (crates/lib/src/scene.rs:33,50).
+ * One-sided rectangular emitter.  64 bytes. */
+typedef struct lpt_light {
+    float normal[4];    /* xyz unit normal (emitting side), w unused        */
+    float tangent[4];   /* xyz unit tangent,   w = half width               */
+    float bitangent[4]; /* xyz unit bitangent, w = half height              */
+    float origin[4];    /* xyz centre,         w = radiance (white)         */
+} lpt_light;
+
+/* replaces: albedo_rtx::uniforms::Instance as built by BLASArray::add_instance
+ * (crates/lib/src/loaders/gltf.rs:141-145) and edited by Instance::set_transform
+ * (crates/standalone/src/lib.rs:117-121). */
+typedef struct lpt_instance {
+    float model_to_world[16];
+    uint32_t blas_index;
+    uint32_t material_index;
+    uint32_t pad[2];
+} lpt_instance;
+
+/* replaces: one BLASArray.entries element (crates/lib/src/scene.rs:43-49). */
+typedef struct lpt_blas_entry {
+    uint32_t vertex_offset; /* first vertex in Scene.vertices          */
+    uint32_t vertex_count;
+    uint32_t index_offset;  /* first index in the scene index pool     */
+    uint32_t index_count;   /* 3 * triangle count                      */
+} lpt_blas_entry;
+
+typedef struct lpt_scene_counts {
+    uint32_t materials, entries, vertices, indices, instances, lights, images;
+} lpt_scene_counts;
+
+typedef struct lpt_accel_stats {
+    uint32_t triangles;  /* baked world-space triangles                 */
+    uint32_t nodes;      /* wide-BVH nodes                              */
+    uint32_t node_bytes; /* bytes per node                              */
+    uint32_t tri_bytes;  /* bytes per pre-transformed triangle          */
+    uint32_t max_depth;
+    float build_ms;
+} lpt_accel_stats;
+
+/* result of a closest-hit query (the build's `Intersection`, 16 bytes) */
+typedef struct lpt_hit {
+    float t, u, v;
+    uint32_t prim; /* baked triangle id, 0x80000000|light for an emitter, LPT_INVALID_INDEX on miss */
+} lpt_hit;
+
+typedef struct lpt_ray_counts {
+    uint64_t closest; /* closest-hit rays traced since the last reset */
+    uint64_t shadow;  /* shadow (any-hit) rays traced                 */
+    uint64_t shaded;  /* surface hits shaded                          */
+    uint64_t nodes;   /* BVH nodes visited (only when stats enabled)  */
+    uint64_t tris;    /* triangles tested  (only when stats enabled)  */
+} lpt_ray_counts;
+
+typedef struct lpt_timing {
+    char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation" */
+    float ms;       /* summed over the last raytrace() call */
+    uint32_t launches;
+} lpt_timing;
+
+/* replaces: enum BlitMode (crates/lib/src/renderer.rs:160-167; spelling of
+ * `Pahtrace` is the reference's). */
+enum {
+    LPT_BLIT_PATHTRACE = 0,
+    LPT_BLIT_DENOISED = 1,
+    LPT_BLIT_TEMPORAL = 2,
+    LPT_BLIT_GBUFFER = 3,
+    LPT_BLIT_MOTION = 4
+};
+
+typedef struct lpt_device lpt_device;
+typedef struct lpt_scene lpt_scene;
+typedef struct lpt_scene_gpu lpt_scene_gpu;
+typedef struct lpt_probe lpt_probe;
+typedef struct lpt_renderer lpt_renderer;
+
+/* ---- Device ---------------------------------------------------------------
+ * replaces: Device::new(wgpu::Device) (crates/lib/src/device.rs:80).  One
+ * process drives one GPU; `hip_ordinal` picks it.  Fails with LPT_ERR_HIP when
+ * no gfx950 device is visible — there is no CPU fallback. */
+int lpt_device_create(int hip_ordinal, lpt_device **out);
+int lpt_device_destroy(lpt_device *dev);
+int lpt_device_synchronize(lpt_device *dev);
+/* name, CU count and the HIP stream handle (void*: a hipStream_t) the renderer
+ * enqueues on — bench.py brackets that stream with HIP events. */
+int lpt_device_info(lpt_device *dev, char *name, size_t name_cap, int *compute_units);
+int lpt_device_stream(lpt_device *dev, void **hip_stream);
+
+/* ---- Scene (CPU side) -----------------------------------------------------
+ * replaces: Scene::default() and its pub fields (crates/lib/src/scene.rs:30-54).
+ * As in the reference, a fresh scene holds ONE dummy element in every array
+ * (material 0, BLAS entry 0, vertex 0, instance 0, light 0 = Light::new()), so
+ * loaded content starts at index 1 (crates/standalone/src/lib.rs:117). */
+int lpt_scene_create(lpt_scene **out);
+int lpt_scene_destroy(lpt_scene *scene);
+int lpt_scene_counts_get(const lpt_scene *scene, lpt_scene_counts *out);
+
+/* replaces: BLASArray::add_bvh(MeshDescriptor) / add_bvh_indexed(IndexedMeshDescriptor)
+ * (crates/lib/src/loaders/gltf.rs:91-105).  Strides are in BYTES (pas::Slice);
+ * positions may be vec3 or vec4 (only xyz read); normals / uvs / indices may be
+ * NULL.  Without indices, vertices are consumed three at a time.  Missing
+ * normals become flat face normals (crates/lib/src/loaders/binary.rs:31-49).
+ * LPT_ERR_ACCEL_BUILD on an out-of-range index or a count that is not a
+ * multiple of three. */
+int lpt_scene_add_mesh(lpt_scene *scene, const void *positions, size_t position_stride,
+                       const void *normals, size_t normal_stride, const void *uvs,
+                       size_t uv_stride, uint32_t vertex_count, const uint32_t *indices,
+                       uint32_t index_count, uint32_t *out_blas_index);
+/* replaces: BLASArray::add_instance(blas, model_to_world, material)
+ * (crates/lib/src/loaders/gltf.rs:141-145). */
+int lpt_scene_add_instance(lpt_scene *scene, uint32_t blas_index, const float model_to_world[16],
+                           uint32_t material_index, uint32_t *out_instance_index);
+/* replaces: Instance::set_transform (crates/standalone/src/lib.rs:118-121). */
+int lpt_scene_set_instance_transform(lpt_scene *scene, uint32_t instance_index,
+                                     const float model_to_world[16]);
+/* replaces: scene.materials.push(..) (crates/lib/src/loaders/gltf.rs:113) */
+int lpt_scene_add_material(lpt_scene *scene, const lpt_material *m, uint32_t *out_index);
+/* replaces: scene.images.push(ImageData::new(rgba8,w,h)) (gltf.rs:150-153) */
+int lpt_scene_add_image(lpt_scene *scene, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                        uint32_t *out_index);
+/* replaces: pub lights: Vec<Light> (crates/lib/src/scene.rs:33) */
+int lpt_scene_add_light(lpt_scene *scene, const lpt_light *l, uint32_t *out_index);
+int lpt_scene_set_light(lpt_scene *scene, uint32_t index, const lpt_light *l);
+/* replaces: Light::new() (crates/lib/src/scene.rs:50) */
+int lpt_light_default(lpt_light *out);
+
+/* Read-back of the flat arrays (the reference exposes them as pub Vec fields). */
+int lpt_scene_get_materials(const lpt_scene *s, uint32_t first, uint32_t count, lpt_material *dst);
+int lpt_scene_get_entries(const lpt_scene *s, uint32_t first, uint32_t count, lpt_blas_entry *dst);
+int lpt_scene_get_vertices(const lpt_scene *s, uint32_t first, uint32_t count, lpt_vertex *dst);
+int lpt_scene_get_indices(const lpt_scene *s, uint32_t first, uint32_t count, uint32_t *dst);
+int lpt_scene_get_instances(const lpt_scene *s, uint32_t first, uint32_t count, lpt_instance *dst);
+int lpt_scene_get_lights(const lpt_scene *s, uint32_t first, uint32_t count, lpt_light *dst);
+int lpt_scene_get_image(const lpt_scene *s, uint32_t index, uint32_t *width, uint32_t *height,
+                        uint8_t *dst_rgba8 /* may be NULL to query the size */);
+
+/* ---- loaders --------------------------------------------------------------
+ * replaces: loaders::load_gltf(&[u8], &mut Scene) -> Result<(), Error>
+ * (crates/lib/src/loaders/gltf.rs:46-156).  Accepts .glb or .gltf JSON with
+ * embedded (data: URI) buffers; appends to `scene` with the reference's offset
+ * rules (:60,109-110).  LPT_ERR_FILE_NOT_FOUND on any parse failure (:49-53). */
+int lpt_load_gltf(lpt_scene *scene, const uint8_t *data, size_t size);
+/* replaces: loaders::load_gltf_path (gltf.rs:158-161) */
+int lpt_load_gltf_path(lpt_scene *scene, const char *path);
+
+/* ---- SceneGPU / ProbeGPU --------------------------------------------------
+ * replaces: SceneGPU::new_from_scene(&Scene,&Device,&Queue)
+ * (crates/lib/src/scene.rs:151-188).  Bakes every instance into world space,
+ * builds the wide BVH on the host and copies nodes / triangles / vertices /
+ * materials / lights / image atlas into HBM.  The CPU scene stays with the
+ * caller.  LPT_ERR_ACCEL_BUILD when the build fails. */
+int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out);
+int lpt_scene_gpu_destroy(lpt_scene_gpu *sg);
+int lpt_scene_gpu_stats(const lpt_scene_gpu *sg, lpt_accel_stats *out);
+
+/* replaces: ProbeGPU::new(device, queue, data, width, height)
+ * (crates/lib/src/scene.rs:72-121): 4 bytes/pixel RGBE8, equirectangular. */
+int lpt_probe_upload(lpt_device *dev, const uint8_t *rgbe8, uint32_t width, uint32_t height,
+                     lpt_probe **out);
+int lpt_probe_destroy(lpt_probe *probe);
+
+/* ---- ray queries (the IntersectorPass on its own) -------------------------
+ * replaces: passes::IntersectorPass dispatch (crates/lib/src/renderer.rs:458-463)
+ * applied to caller-supplied rays.  `origins`/`dirs` are n×3 floats on the
+ * HOST; results come back to the host.  Used by the parity tests. */
+int lpt_trace_closest(lpt_device *dev, const lpt_scene_gpu *sg, const float *origins,
+                      const float *dirs, uint32_t n, lpt_hit *out_hits);
+int lpt_trace_occluded(lpt_device *dev, const lpt_scene_gpu *sg, const float *origins,
+                       const float *dirs, const float *tmax, uint32_t n, uint8_t *out_occluded);
+
+/* ---- Renderer --------------------------------------------------------------
+ * replaces: Renderer::new(&Device, (w,h), swapchain_format)
+ * (crates/lib/src/renderer.rs:220-324).  Applies downsample_factor 0.5 like
+ * the reference (:225); there is no swapchain. */
+int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_renderer **out);
+int lpt_renderer_destroy(lpt_renderer *r);
+/* replaces: pub downsample_factor (renderer.rs:203).  Takes effect at the next resize. */
+int lpt_renderer_set_downsample(lpt_renderer *r, float factor);
+/* replaces: Renderer::resize(&Device,&SceneGPU,Option<&ProbeGPU>,(w,h)) (renderer.rs:326-358) */
+int lpt_renderer_resize(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe_or_null,
+                        uint32_t width, uint32_t height);
+/* replaces: Renderer::get_size (renderer.rs:683) — the path-traced size */
+int lpt_renderer_get_size(const lpt_renderer *r, uint32_t *width, uint32_t *height);
+/* replaces: Renderer::max_ssbo_element_in_bytes (renderer.rs:209-218) */
+uint32_t lpt_max_per_pixel_bytes(void);
+/* replaces: Renderer::set_resources(&Device,&SceneGPU,Option<&ProbeGPU>)
+ * (renderer.rs:687-725); resets frame_count to 1 (:724); a NULL probe is the
+ * 1×1 default texture, i.e. a black environment (:693-696, device.rs:13-26). */
+int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg,
+                               const lpt_probe *probe_or_null);
+/* replaces: Renderer::raytrace(&mut encoder,&queue,&Mat4) (renderer.rs:392-549).
+ * Enqueues ONE sample per pixel on the renderer's stream and returns without
+ * waiting ("record now, submit later").  `view_transform` is camera-to-world
+ * (crates/standalone/src/camera.rs:101-108).  Returns LPT_OK and does nothing
+ * when resources are unset (renderer.rs:403-407,419-422). */
+int lpt_renderer_raytrace(lpt_renderer *r, const float view_transform[16]);
+/* replaces: Renderer::reset_accumulation (renderer.rs:609-618) */
+int lpt_renderer_reset_accumulation(lpt_renderer *r);
+/* replaces: pub accumulate (renderer.rs:204; set by the app at app.rs:318) */
+int lpt_renderer_set_accumulate(lpt_renderer *r, int accumulate);
+int lpt_renderer_get_accumulate(const lpt_renderer *r, int *accumulate);
+/* replaces: global_uniforms.{frame_count,seed} (renderer.rs:286-290) — read-only view */
+int lpt_renderer_get_frame_state(const lpt_renderer *r, uint32_t *frame_count, uint32_t *seed);
+/* replaces: Renderer::upload_noise_texture (renderer.rs:620-664) */
+int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t width,
+                              uint32_t height, uint32_t bytes_per_row);
+/* replaces: Renderer::use_noise_texture(&queue,bool) (renderer.rs:666-673) */
+int lpt_renderer_use_noise(lpt_renderer *r, int flag);
+/* replaces: Renderer::set_blit_mode (renderer.rs:675-681) */
+int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode);
+/* replaces: Renderer::blit(&Device,&mut encoder,&TextureView) (renderer.rs:551-607):
+ * tonemapped sRGB RGBA8 of the current target into caller memory. */
+int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes);
+/* replaces: async Renderer::read_pixels -> Result<Vec<u8>,Error> (renderer.rs:727-811).
+ * Blocking (the reference's device.poll(Wait), :791); w*h*4 bytes, tight rows. */
+int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst);
+/* Parity surface (no reference twin): mean radiance, w*h*4 floats, a = 1 where
+ * this process owns the pixel and has accumulated at least one sample. */
+int lpt_renderer_read_radiance(lpt_renderer *r, float *dst);
+/* replaces: renderer.queries.values()/labels()
+ * (crates/standalone/src/gui/windows/performance_info.rs:19-20) */
+int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count);
+int lpt_renderer_enable_timings(lpt_renderer *r, int flag);
+
+/* ---- build-only extensions (no reference knob) -------- */
+/* reference constant STATIC/MOVING_NUM_BOUNCES = 3 (renderer.rs:398-399) */
+int lpt_renderer_set_max_bounces(lpt_renderer *r, uint32_t bounces);
+int lpt_renderer_set_seed(lpt_renderer *r, uint32_t user_seed);
+/* vertical field of view in radians (reference: Camera::default inside albedo) */
+int lpt_renderer_set_vfov(lpt_renderer *r, float radians);
+/* Pixel-tile sharding for one-process-per-GPU rendering: this process traces
+ * the tiles whose index (row-major over ceil(w/tile_w) × ceil(h/tile_h)) is
+ * ≡ rank (mod world_size).  Default (0,1,32,8) = everything. */
+int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world_size, uint32_t tile_w,
+                           uint32_t tile_h);
+/* Device address + byte size of the fp32 RGBA accumulation buffer
+ * (rgb = radiance SUM, a = sample count; zero where not owned).  The collective
+ * layer sums it across ranks (RCCL reduce) before read_radiance on rank 0. */
+int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **device_ptr, size_t *bytes);
+int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
+int lpt_renderer_reset_ray_counts(lpt_renderer *r);
+/* count BVH nodes visited / triangles tested per ray (slower kernel variant) */
+int lpt_renderer_enable_stats(lpt_renderer *r, int flag);
+int lpt_renderer_synchronize(lpt_renderer *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPT_H */
