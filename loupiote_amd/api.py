@@ -1,0 +1,417 @@
+"""Host-side mirror of the reference's `loupiote-core` API over the C ABI.
+
+Same names, argument meaning and error behaviour as reference crates/lib/src:
+``Device`` (device.rs:72-141), ``Scene`` / ``SceneGPU`` / ``ProbeGPU`` (scene.rs:30-188),
+``Renderer`` / ``BlitMode`` (renderer.rs:160-811), ``Error`` (errors.rs:1-20) and
+``loaders.load_gltf`` (loaders/gltf.rs:46-161).  wgpu handles (device, queue, encoder,
+texture view) have no meaning here and are dropped from the signatures; everything else is
+forwarded 1:1 to ``lpt_*``.  No arithmetic happens in this file.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _abi as A
+
+
+class Error(Exception):
+    """errors.rs:2-6 — FileNotFound / TextureToBufferReadFail / AccelBuild (+ the ABI's own codes)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+        self.kind = {A.LPT_ERR_FILE_NOT_FOUND: "FileNotFound", A.LPT_ERR_READBACK: "TextureToBufferReadFail",
+                     A.LPT_ERR_ACCEL_BUILD: "AccelBuild", A.LPT_ERR_HIP: "Hip", A.LPT_ERR_RCCL: "Rccl",
+                     A.LPT_ERR_INVALID_ARG: "InvalidArg"}.get(status, "Unknown")
+
+
+def _check(status):
+    if status != A.LPT_OK:
+        raise Error(status, A.lib().lpt_last_error().decode("utf-8", "replace"))
+
+
+class BlitMode(enum.IntEnum):
+    """renderer.rs:160-167 (spelling `Pahtrace` is the reference's)."""
+    Pahtrace = 0
+    DenoisedPathrace = 1
+    Temporal = 2
+    GBuffer = 3
+    MotionVector = 4
+
+
+class Device:
+    """device.rs:80 `Device::new(wgpu::Device)` -> one HIP device + the stream all work is enqueued on."""
+
+    def __init__(self, hip_ordinal=0):
+        h = C.c_void_p()
+        _check(A.lib().lpt_device_create(int(hip_ordinal), C.byref(h)))
+        self._h = h
+
+    def inner(self):
+        return self._h
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus = C.c_int()
+        _check(A.lib().lpt_device_info(self._h, name, 128, C.byref(cus)))
+        return name.value.decode(), cus.value
+
+    def stream(self):
+        s = C.c_void_p()
+        _check(A.lib().lpt_device_stream(self._h, C.byref(s)))
+        return s.value
+
+    def synchronize(self):
+        _check(A.lib().lpt_device_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            A.lib().lpt_device_destroy(self._h)
+            self._h = None
+
+
+class Scene:
+    """scene.rs:30-54 — `Scene::default()` holds one dummy element in every array."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(A.lib().lpt_scene_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                A.lib().lpt_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def counts(self):
+        c = A.SceneCounts()
+        _check(A.lib().lpt_scene_counts_get(self._h, C.byref(c)))
+        return c
+
+    # BLASArray::add_bvh / add_bvh_indexed (gltf.rs:97-105)
+    def add_mesh(self, positions, normals=None, uvs=None, indices=None):
+        pos = np.ascontiguousarray(positions, np.float32)
+        n = pos.shape[0]
+        nrm = None if normals is None else np.ascontiguousarray(normals, np.float32)
+        uv = None if uvs is None else np.ascontiguousarray(uvs, np.float32)
+        idx = None if indices is None else np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        out = C.c_uint32()
+        _check(A.lib().lpt_scene_add_mesh(self._h, A.ptr(pos), pos.strides[0], A.ptr(nrm), 0 if nrm is None else nrm.strides[0],
+                                          A.ptr(uv), 0 if uv is None else uv.strides[0], n, A.ptr(idx),
+                                          0 if idx is None else idx.size, C.byref(out)))
+        return out.value
+
+    # BLASArray::add_instance (gltf.rs:141-145)
+    def add_instance(self, blas_index, model_to_world, material_index):
+        m = np.ascontiguousarray(model_to_world, np.float32).reshape(16)
+        out = C.c_uint32()
+        _check(A.lib().lpt_scene_add_instance(self._h, int(blas_index), A.ptr(m), int(material_index), C.byref(out)))
+        return out.value
+
+    def set_instance_transform(self, index, model_to_world):
+        m = np.ascontiguousarray(model_to_world, np.float32).reshape(16)
+        _check(A.lib().lpt_scene_set_instance_transform(self._h, int(index), A.ptr(m)))
+
+    def add_material(self, color, roughness, reflectivity, albedo_texture=A.INVALID_INDEX, mra_texture=A.INVALID_INDEX):
+        m = np.zeros(1, A.MATERIAL_DT)
+        m["color"] = color
+        m["roughness"] = roughness
+        m["reflectivity"] = reflectivity
+        m["albedo_texture"] = albedo_texture
+        m["mra_texture"] = mra_texture
+        out = C.c_uint32()
+        _check(A.lib().lpt_scene_add_material(self._h, A.ptr(m), C.byref(out)))
+        return out.value
+
+    def add_image(self, rgba8):
+        im = np.ascontiguousarray(rgba8, np.uint8)
+        out = C.c_uint32()
+        _check(A.lib().lpt_scene_add_image(self._h, A.ptr(im), im.shape[1], im.shape[0], C.byref(out)))
+        return out.value
+
+    def add_light(self, light):
+        l = np.ascontiguousarray(light, A.LIGHT_DT).reshape(1)
+        out = C.c_uint32()
+        _check(A.lib().lpt_scene_add_light(self._h, A.ptr(l), C.byref(out)))
+        return out.value
+
+    def set_light(self, index, light):
+        l = np.ascontiguousarray(light, A.LIGHT_DT).reshape(1)
+        _check(A.lib().lpt_scene_set_light(self._h, int(index), A.ptr(l)))
+
+    def _get(self, fn, dt, count):
+        out = np.zeros(count, dt)
+        _check(fn(self._h, 0, count, A.ptr(out)))
+        return out
+
+    @property
+    def materials(self):
+        return self._get(A.lib().lpt_scene_get_materials, A.MATERIAL_DT, self.counts().materials)
+
+    @property
+    def entries(self):
+        return self._get(A.lib().lpt_scene_get_entries, A.ENTRY_DT, self.counts().entries)
+
+    @property
+    def vertices(self):
+        return self._get(A.lib().lpt_scene_get_vertices, A.VERTEX_DT, self.counts().vertices)
+
+    @property
+    def indices(self):
+        return self._get(A.lib().lpt_scene_get_indices, np.uint32, self.counts().indices)
+
+    @property
+    def instances(self):
+        return self._get(A.lib().lpt_scene_get_instances, A.INSTANCE_DT, self.counts().instances)
+
+    @property
+    def lights(self):
+        return self._get(A.lib().lpt_scene_get_lights, A.LIGHT_DT, self.counts().lights)
+
+    def image(self, index):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(A.lib().lpt_scene_get_image(self._h, index, C.byref(w), C.byref(h), None))
+        out = np.zeros((h.value, w.value, 4), np.uint8)
+        _check(A.lib().lpt_scene_get_image(self._h, index, None, None, A.ptr(out)))
+        return out
+
+
+def default_light():
+    """`Light::new()` (scene.rs:50)."""
+    l = np.zeros(1, A.LIGHT_DT)
+    _check(A.lib().lpt_light_default(A.ptr(l)))
+    return l
+
+
+class SceneGPU:
+    """scene.rs:151 `SceneGPU::new_from_scene(&Scene, &Device, &Queue)`."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self._dev = device
+
+    @classmethod
+    def new_from_scene(cls, scene, device):
+        h = C.c_void_p()
+        _check(A.lib().lpt_scene_upload(device.inner(), scene._h, C.byref(h)))
+        return cls(h, device)
+
+    def stats(self):
+        s = A.AccelStats()
+        _check(A.lib().lpt_scene_gpu_stats(self._h, C.byref(s)))
+        return s
+
+    def trace_closest(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        out = np.zeros(o.shape[0], A.HIT_DT)
+        _check(A.lib().lpt_trace_closest(self._dev.inner(), self._h, A.ptr(o), A.ptr(d), o.shape[0], A.ptr(out)))
+        return out
+
+    def trace_occluded(self, origins, dirs, tmax):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        t = np.ascontiguousarray(tmax, np.float32)
+        out = np.zeros(o.shape[0], np.uint8)
+        _check(A.lib().lpt_trace_occluded(self._dev.inner(), self._h, A.ptr(o), A.ptr(d), A.ptr(t), o.shape[0], A.ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            A.lib().lpt_scene_gpu_destroy(self._h)
+            self._h = None
+
+
+class ProbeGPU:
+    """scene.rs:72 `ProbeGPU::new(device, queue, data, width, height)` — RGBE8, 4 bytes per pixel."""
+
+    def __init__(self, device, data, width, height):
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data, np.uint8)
+        if buf.size != width * height * 4:
+            raise Error(A.LPT_ERR_INVALID_ARG, "probe data must be width*height*4 bytes")
+        h = C.c_void_p()
+        _check(A.lib().lpt_probe_upload(device.inner(), A.ptr(buf), width, height, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            A.lib().lpt_probe_destroy(self._h)
+            self._h = None
+
+
+class Renderer:
+    """renderer.rs:169-811."""
+
+    def __init__(self, device, original_size, swapchain_format=None):
+        h = C.c_void_p()
+        _check(A.lib().lpt_renderer_create(device.inner(), int(original_size[0]), int(original_size[1]), C.byref(h)))
+        self._h = h
+        self._dev = device
+        self._downsample = 0.5
+
+    @staticmethod
+    def max_ssbo_element_in_bytes():
+        return A.lib().lpt_max_per_pixel_bytes()
+
+    # pub downsample_factor (renderer.rs:203)
+    @property
+    def downsample_factor(self):
+        return self._downsample
+
+    @downsample_factor.setter
+    def downsample_factor(self, f):
+        _check(A.lib().lpt_renderer_set_downsample(self._h, float(f)))
+        self._downsample = float(f)
+
+    # pub accumulate (renderer.rs:204)
+    @property
+    def accumulate(self):
+        a = C.c_int()
+        _check(A.lib().lpt_renderer_get_accumulate(self._h, C.byref(a)))
+        return bool(a.value)
+
+    @accumulate.setter
+    def accumulate(self, flag):
+        _check(A.lib().lpt_renderer_set_accumulate(self._h, int(bool(flag))))
+
+    def resize(self, device, scene_resources, probe, size):
+        _check(A.lib().lpt_renderer_resize(self._h, scene_resources._h, probe._h if probe is not None else None,
+                                           int(size[0]), int(size[1])))
+
+    def get_size(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(A.lib().lpt_renderer_get_size(self._h, C.byref(w), C.byref(h)))
+        return (w.value, h.value)
+
+    def set_resources(self, device, scene_resources, probe=None):
+        _check(A.lib().lpt_renderer_set_resources(self._h, scene_resources._h, probe._h if probe is not None else None))
+
+    def raytrace(self, view_transform):
+        m = np.ascontiguousarray(view_transform, np.float32).reshape(16)
+        _check(A.lib().lpt_renderer_raytrace(self._h, A.ptr(m)))
+
+    def reset_accumulation(self):
+        _check(A.lib().lpt_renderer_reset_accumulation(self._h))
+
+    def upload_noise_texture(self, data, width, height, bytes_per_row):
+        buf = np.ascontiguousarray(data, np.uint8)
+        _check(A.lib().lpt_renderer_upload_noise(self._h, A.ptr(buf), width, height, bytes_per_row))
+
+    def use_noise_texture(self, flag):
+        _check(A.lib().lpt_renderer_use_noise(self._h, int(bool(flag))))
+
+    def set_blit_mode(self, mode):
+        _check(A.lib().lpt_renderer_set_blit_mode(self._h, int(mode)))
+
+    def blit(self):
+        w, h = self.get_size()
+        out = np.zeros((h, w, 4), np.uint8)
+        _check(A.lib().lpt_renderer_blit_rgba8(self._h, A.ptr(out), w * 4))
+        return out
+
+    def read_pixels(self):
+        w, h = self.get_size()
+        out = np.zeros((h, w, 4), np.uint8)
+        _check(A.lib().lpt_renderer_read_pixels(self._h, A.ptr(out)))
+        return out
+
+    # ---- build-only extensions
+    def read_radiance(self):
+        w, h = self.get_size()
+        out = np.zeros((h, w, 4), np.float32)
+        _check(A.lib().lpt_renderer_read_radiance(self._h, A.ptr(out)))
+        return out
+
+    def frame_state(self):
+        fc, seed = C.c_uint32(), C.c_uint32()
+        _check(A.lib().lpt_renderer_get_frame_state(self._h, C.byref(fc), C.byref(seed)))
+        return fc.value, seed.value
+
+    def set_max_bounces(self, n):
+        _check(A.lib().lpt_renderer_set_max_bounces(self._h, int(n)))
+
+    def set_seed(self, s):
+        _check(A.lib().lpt_renderer_set_seed(self._h, int(s)))
+
+    def set_vfov(self, radians):
+        _check(A.lib().lpt_renderer_set_vfov(self._h, float(radians)))
+
+    def set_shard(self, rank, world_size, tile_w=32, tile_h=8):
+        _check(A.lib().lpt_renderer_set_shard(self._h, rank, world_size, tile_w, tile_h))
+
+    def radiance_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(A.lib().lpt_renderer_radiance_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def ray_counts(self):
+        c = A.RayCounts()
+        _check(A.lib().lpt_renderer_get_ray_counts(self._h, C.byref(c)))
+        return c
+
+    def reset_ray_counts(self):
+        _check(A.lib().lpt_renderer_reset_ray_counts(self._h))
+
+    def enable_stats(self, flag):
+        _check(A.lib().lpt_renderer_enable_stats(self._h, int(bool(flag))))
+
+    def enable_timings(self, flag):
+        _check(A.lib().lpt_renderer_enable_timings(self._h, int(bool(flag))))
+
+    def timings(self):
+        n = C.c_int(8)
+        arr = (A.Timing * 8)()
+        _check(A.lib().lpt_renderer_get_timings(self._h, arr, C.byref(n)))
+        return {arr[i].label.decode(): (arr[i].ms, arr[i].launches) for i in range(min(n.value, 8))}
+
+    def synchronize(self):
+        _check(A.lib().lpt_renderer_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            A.lib().lpt_renderer_destroy(self._h)
+            self._h = None
+
+
+class loaders:
+    """crates/lib/src/loaders/mod.rs"""
+
+    @staticmethod
+    def load_gltf(data, scene):
+        buf = np.frombuffer(bytes(data), np.uint8)
+        _check(A.lib().lpt_load_gltf(scene._h, A.ptr(buf), buf.size))
+
+    @staticmethod
+    def load_gltf_path(path, scene):
+        _check(A.lib().lpt_load_gltf_path(scene._h, str(path).encode()))
+
+
+class CameraController:
+    """Convention-only mirror of crates/standalone/src/camera.rs:46-116: `update()` returns the
+    camera-to-world Mat4 = T(origin) * [right up direction W] (column-major, 16 floats)."""
+
+    def __init__(self, origin=(0.0, 0.0, 0.0), direction=(0.0, 0.0, -1.0)):
+        self.origin = np.asarray(origin, np.float32)
+        self.direction = np.asarray(direction, np.float32)
+
+    @classmethod
+    def from_origin_dir(cls, origin, direction):
+        return cls(origin, direction)
+
+    def update(self, delta=0.0):
+        d = self.direction / np.float32(np.sqrt(np.dot(self.direction, self.direction)))
+        right = np.cross(d, np.array([0, 1, 0], np.float32)).astype(np.float32)
+        right /= np.float32(np.sqrt(np.dot(right, right)))
+        up = np.cross(right, d).astype(np.float32)
+        up /= np.float32(np.sqrt(np.dot(up, up)))
+        m = np.zeros((4, 4), np.float32)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, up, d, self.origin
+        m[3, 3] = 1.0
+        return m.T.reshape(16).copy()
+
+    def is_static(self):
+        return True

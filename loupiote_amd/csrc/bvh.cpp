@@ -1,0 +1,284 @@
+// bvh.cpp — instance baking, host BVH construction and triangle pre-transform.
+//
+// Replaces what the reference delegates to albedo_rtx::BLASArray::add_bvh(_indexed)
+// (reference crates/lib/src/loaders/gltf.rs:97-105 -> tinybvh-rs / obvhs, both absent
+// from the reference tree): the acceleration structure the IntersectorPass walks.
+// Instead of per-BLAS trees plus a linear instance loop, every instance is baked into
+// world space (SPEC §2.5) and ONE tree is built over all triangles.
+//
+//   builder : binned SAH (16 bins / axis), leaves <= 4 triangles, depth-capped so the
+//             traversal stack has a hard bound (falls back to median splits).
+//   layout  : Node2 — each 64-byte node stores BOTH children's boxes, so one fetch
+//             decides two subtrees.  Leaves index a run of Woop-transformed triangles.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "common.h"
+
+namespace lpt {
+
+// SPEC §6 — computed in double, rounded to fp32 once.
+void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3], WoopTri &w) {
+    const double ax = p0[0], ay = p0[1], az = p0[2];
+    const double e1x = (double)p1[0] - ax, e1y = (double)p1[1] - ay, e1z = (double)p1[2] - az;
+    const double e2x = (double)p2[0] - ax, e2y = (double)p2[1] - ay, e2z = (double)p2[2] - az;
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double det = nx * nx + ny * ny + nz * nz;
+    if (!(det > 0.0)) { memset(&w, 0, sizeof w); return; }
+    const double inv = 1.0 / det;
+    const double r0x = (e2y * nz - e2z * ny) * inv, r0y = (e2z * nx - e2x * nz) * inv, r0z = (e2x * ny - e2y * nx) * inv;
+    const double r1x = (ny * e1z - nz * e1y) * inv, r1y = (nz * e1x - nx * e1z) * inv, r1z = (nx * e1y - ny * e1x) * inv;
+    const double r2x = nx * inv, r2y = ny * inv, r2z = nz * inv;
+    w.r0[0] = (float)r0x; w.r0[1] = (float)r0y; w.r0[2] = (float)r0z; w.r0[3] = (float)(-(r0x * ax + r0y * ay + r0z * az));
+    w.r1[0] = (float)r1x; w.r1[1] = (float)r1y; w.r1[2] = (float)r1z; w.r1[3] = (float)(-(r1x * ax + r1y * ay + r1z * az));
+    w.r2[0] = (float)r2x; w.r2[1] = (float)r2y; w.r2[2] = (float)r2z; w.r2[3] = (float)(-(r2x * ax + r2y * ay + r2z * az));
+}
+
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kMaxDepth = 30;  // traversal stack is sized from this
+
+struct Box {
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    void grow(const Box &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    void grow(const float p[3]) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0.f) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Ref { Box box; float c[3]; uint32_t prim; };
+
+struct BuildNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; };
+
+struct Builder {
+    std::vector<Ref> refs;
+    std::vector<BuildNode> nodes;
+    uint32_t max_depth = 0;
+
+    static uint32_t ceil_log2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) ++l; return l; }
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+        const int32_t id = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box box, cbox;
+        for (uint32_t i = first; i < first + count; ++i) { box.grow(refs[i].box); cbox.grow(refs[i].c); }
+        nodes[id].box = box;
+        max_depth = std::max(max_depth, depth);
+        if (count <= kLeafMax) { nodes[id].first = first; nodes[id].count = count; return id; }
+
+        // depth budget: below this node we may still need ceil(log2(count/leaf)) median levels
+        const uint32_t need = ceil_log2((count + kLeafMax - 1) / kLeafMax);
+        const bool force_median = depth + need + 1 >= kMaxDepth;
+
+        int best_axis = -1, best_split = -1;
+        float best_cost = 1e30f;
+        if (!force_median) {
+            for (int a = 0; a < 3; ++a) {
+                const float ext = cbox.hi[a] - cbox.lo[a];
+                if (!(ext > 0.f)) continue;
+                Box bb[kBins];
+                uint32_t bc[kBins] = {0};
+                const float scale = (float)kBins / ext;
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = (int)((refs[i].c[a] - cbox.lo[a]) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bb[b].grow(refs[i].box);
+                    bc[b]++;
+                }
+                float right_area[kBins];
+                uint32_t right_cnt[kBins];
+                Box acc;
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+                Box lacc;
+                uint32_t lcnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    lacc.grow(bb[b]);
+                    lcnt += bc[b];
+                    if (!lcnt || !right_cnt[b + 1]) continue;
+                    const float cost = lacc.half_area() * (float)lcnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
+                }
+            }
+        }
+        uint32_t mid = first;
+        if (best_axis >= 0) {
+            const float ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+            const float scale = (float)kBins / ext;
+            const float lo = cbox.lo[best_axis];
+            const int a = best_axis, s = best_split;
+            auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref &r) {
+                int b = (int)((r.c[a] - lo) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                return b <= s;
+            });
+            mid = (uint32_t)(it - refs.begin());
+        }
+        if (mid == first || mid == first + count) {
+            // median split along the widest centroid axis (also the depth-cap path)
+            int a = 0;
+            float ext = cbox.hi[0] - cbox.lo[0];
+            for (int k = 1; k < 3; ++k) if (cbox.hi[k] - cbox.lo[k] > ext) { a = k; ext = cbox.hi[k] - cbox.lo[k]; }
+            mid = first + count / 2;
+            std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + count,
+                             [a](const Ref &x, const Ref &y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.prim < y.prim); });
+        }
+        const int32_t l = build(first, mid - first, depth + 1);
+        const int32_t r = build(mid, first + count - mid, depth + 1);
+        nodes[id].left = l;
+        nodes[id].right = r;
+        return id;
+    }
+};
+
+inline void normalize3(float v[3]) {
+    float l2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (!(l2 > 0.f)) { v[0] = v[1] = v[2] = 0.f; return; }
+    float inv = 1.0f / sqrtf(l2);
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+// SPEC §2.5: instances -> world-space soup
+void bake(const lpt_scene &s, Accel &out) {
+    out.tri_verts.clear();
+    out.tri_material.clear();
+    for (size_t ii = 0; ii < s.instances.size(); ++ii) {
+        const lpt_instance &inst = s.instances[ii];
+        if (inst.blas_index >= s.entries.size()) continue;
+        const lpt_blas_entry &e = s.entries[inst.blas_index];
+        const uint32_t ntri = e.index_count / 3u;
+        if (!ntri) continue;
+        const float *m = inst.model_to_world;
+        const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
+        const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const float c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
+        const float c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
+        uint32_t mi = inst.material_index;
+        if (mi >= s.materials.size()) mi = 0;
+        for (uint32_t t = 0; t < ntri; ++t) {
+            for (int k = 0; k < 3; ++k) {
+                const lpt_vertex &v = s.vertices[e.vertex_offset + s.indices[e.index_offset + 3 * t + k]];
+                const float x = v.position[0], y = v.position[1], z = v.position[2];
+                lpt_vertex o;
+                o.position[0] = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+                o.position[1] = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+                o.position[2] = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+                o.position[3] = v.position[3];
+                const float nx = v.normal[0], ny = v.normal[1], nz = v.normal[2];
+                float n[3] = {(c00 * nx + c01 * ny) + c02 * nz, (c10 * nx + c11 * ny) + c12 * nz, (c20 * nx + c21 * ny) + c22 * nz};
+                normalize3(n);
+                o.normal[0] = n[0]; o.normal[1] = n[1]; o.normal[2] = n[2]; o.normal[3] = v.normal[3];
+                out.tri_verts.push_back(o);
+            }
+            out.tri_material.push_back(mi);
+        }
+    }
+}
+
+// Triangle boxes are padded a little so that the box test stays conservative with
+// respect to the Woop test's own rounding (the slab test adds its own ulp margins).
+Box padded_box(const lpt_vertex *v) {
+    Box b;
+    for (int k = 0; k < 3; ++k) b.grow(v[k].position);
+    for (int a = 0; a < 3; ++a) {
+        const float m = std::max(fabsf(b.lo[a]), fabsf(b.hi[a]));
+        const float e = 4e-6f * m + 1e-6f * (b.hi[a] - b.lo[a]) + 1e-30f;
+        b.lo[a] -= e;
+        b.hi[a] += e;
+    }
+    return b;
+}
+
+}  // namespace
+
+int bake_and_build(const lpt_scene &scene, Accel &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bake(scene, out);
+    const uint32_t n = (uint32_t)out.tri_material.size();
+    out.nodes.clear();
+    out.woop.clear();
+    out.leaf_prim.clear();
+    out.max_depth = 0;
+    if (n >= (1u << 29)) return fail(LPT_ERR_ACCEL_BUILD, "too many triangles (%u)", n);
+    for (uint32_t t = 0; t < n; ++t)
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a)
+                if (!std::isfinite(out.tri_verts[3 * (size_t)t + k].position[a]))
+                    return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in baked triangle %u", t);
+    if (n == 0) {
+        // a single node whose children can never be hit
+        Node2 root;
+        memset(&root, 0, sizeof root);
+        for (int a = 0; a < 3; ++a) { root.lo0[a] = root.lo1[a] = 1e30f; root.hi0[a] = root.hi1[a] = -1e30f; }
+        root.child0 = root.child1 = 0;
+        out.nodes.push_back(root);
+        WoopTri z;
+        memset(&z, 0, sizeof z);
+        out.woop.push_back(z);
+        out.leaf_prim.push_back(LPT_INVALID_INDEX);
+        return LPT_OK;
+    }
+    Builder b;
+    b.refs.resize(n);
+    for (uint32_t t = 0; t < n; ++t) {
+        Ref &r = b.refs[t];
+        r.box = padded_box(&out.tri_verts[3 * (size_t)t]);
+        for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * (r.box.lo[a] + r.box.hi[a]);
+        r.prim = t;
+    }
+    b.nodes.reserve(2 * (size_t)n);
+    b.build(0, n, 0);
+    out.max_depth = b.max_depth;
+
+    // triangles in leaf order
+    out.woop.resize(n);
+    out.leaf_prim.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t p = b.refs[i].prim;
+        out.leaf_prim[i] = p;
+        const lpt_vertex *v = &out.tri_verts[3 * (size_t)p];
+        woop_from_triangle(v[0].position, v[1].position, v[2].position, out.woop[i]);
+    }
+    // Node2 layout: inner build nodes only; leaves become negative child references
+    std::vector<int32_t> remap(b.nodes.size(), -1);
+    int32_t n_inner = 0;
+    for (size_t i = 0; i < b.nodes.size(); ++i)
+        if (b.nodes[i].count == 0) remap[i] = n_inner++;
+    auto child_ref = [&](int32_t id) -> int32_t {
+        const BuildNode &c = b.nodes[id];
+        if (c.count) return ~(int32_t)((c.first << 2) | (c.count - 1u));
+        return remap[id];
+    };
+    if (n_inner == 0) {
+        // the root itself is a leaf: wrap it
+        Node2 root;
+        memset(&root, 0, sizeof root);
+        const BuildNode &r = b.nodes[0];
+        for (int a = 0; a < 3; ++a) { root.lo0[a] = r.box.lo[a]; root.hi0[a] = r.box.hi[a]; root.lo1[a] = 1e30f; root.hi1[a] = -1e30f; }
+        root.child0 = child_ref(0);
+        root.child1 = root.child0;
+        out.nodes.push_back(root);
+    } else {
+        out.nodes.resize((size_t)n_inner);
+        for (size_t i = 0; i < b.nodes.size(); ++i) {
+            if (remap[i] < 0) continue;
+            const BuildNode &bn = b.nodes[i];
+            Node2 &o = out.nodes[(size_t)remap[i]];
+            memset(&o, 0, sizeof o);
+            const BuildNode &l = b.nodes[bn.left], &r = b.nodes[bn.right];
+            for (int a = 0; a < 3; ++a) { o.lo0[a] = l.box.lo[a]; o.hi0[a] = l.box.hi[a]; o.lo1[a] = r.box.lo[a]; o.hi1[a] = r.box.hi[a]; }
+            o.child0 = child_ref(bn.left);
+            o.child1 = child_ref(bn.right);
+        }
+    }
+    out.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return LPT_OK;
+}
+
+}  // namespace lpt

@@ -1,0 +1,71 @@
+// common.h — internal declarations shared by the host-side translation units of
+// libloupiote_hip.so.  Nothing here is part of the ABI (include/lpt.h is).
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lpt.h"
+
+namespace lpt {
+
+// thread-local error text behind lpt_last_error()
+void set_error(const char *fmt, ...);
+int fail(int status, const char *fmt, ...);
+
+struct Image {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> rgba8;
+};
+
+}  // namespace lpt
+
+// The CPU-side scene: the flat arrays of the reference's Scene / BLASArray
+// (reference crates/lib/src/scene.rs:30-54).
+struct lpt_scene {
+    std::vector<lpt_material> materials;
+    std::vector<lpt_blas_entry> entries;
+    std::vector<lpt_vertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<lpt_instance> instances;
+    std::vector<lpt_light> lights;
+    std::vector<lpt::Image> images;
+};
+
+namespace lpt {
+
+// ---- baked, device-ready acceleration data (host copies) -------------------
+struct alignas(16) Node2 {  // 64 B: both children's boxes live in the parent
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;  // >=0 inner node; <0: leaf = ~((first << 2) | (count - 1))
+    int32_t pad[2];
+};
+static_assert(sizeof(Node2) == 64, "Node2 must be 64 bytes");
+
+struct alignas(16) WoopTri {  // 48 B world -> unit-triangle affine map
+    float r0[4], r1[4], r2[4];
+};
+static_assert(sizeof(WoopTri) == 48, "WoopTri must be 48 bytes");
+
+struct Accel {
+    std::vector<lpt_vertex> tri_verts;   // 3 per baked triangle (world space)
+    std::vector<uint32_t> tri_material;  // per baked triangle
+    std::vector<Node2> nodes;            // node 0 = root
+    std::vector<WoopTri> woop;           // in leaf order
+    std::vector<uint32_t> leaf_prim;     // leaf slot -> baked triangle id
+    uint32_t max_depth = 0;
+    float build_ms = 0.f;
+};
+
+// bvh.cpp
+int bake_and_build(const lpt_scene &scene, Accel &out);
+void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3], WoopTri &w);
+
+// png.cpp
+bool decode_png(const uint8_t *data, size_t size, Image &out);
+
+}  // namespace lpt

@@ -1,0 +1,668 @@
+// device.hip — Device / SceneGPU / ProbeGPU / Renderer behind the C ABI (include/lpt.h).
+//
+// Host orchestration of one frame follows Renderer::raytrace
+// (reference crates/lib/src/renderer.rs:392-549): pass order, the seed / bounces /
+// frame_count protocol and the accumulate flag.  Everything is enqueued on ONE HIP
+// stream owned by the device handle and nothing here waits for the GPU except the
+// read-back calls (the reference's only blocking point is read_pixels, :791).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace lpt;
+using namespace lptd;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail(LPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct lpt_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    int compute_units = 0;
+    char name[128] = {0};
+};
+
+struct lpt_scene_gpu {
+    lpt_device *dev = nullptr;
+    DScene d{};
+    void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr, *tri_material = nullptr;
+    void *materials = nullptr, *lights = nullptr, *texels = nullptr, *images = nullptr, *srgb_lut = nullptr;
+    lpt_accel_stats stats{};
+};
+
+struct lpt_probe {
+    lpt_device *dev = nullptr;
+    DProbe d{};
+    void *rgbe = nullptr;
+};
+
+enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_COUNT };
+static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation"};
+
+struct lpt_renderer {
+    lpt_device *dev = nullptr;
+    uint32_t req_w = 0, req_h = 0, w = 0, h = 0;
+    float downsample = 0.5f;
+    const lpt_scene_gpu *sg = nullptr;
+    const lpt_probe *probe = nullptr;
+    bool resources_set = false;
+    // global_uniforms (renderer.rs:286-290)
+    uint32_t frame_count = 1, seed = 0;
+    bool accumulate = false, frame_back = true;
+    int mode = LPT_BLIT_PATHTRACE;
+    // build-only knobs
+    uint32_t max_bounces = 3, user_seed = 0;
+    float vfov = 0.78539816339744830962f;
+    uint32_t rank = 0, world = 1, tile_w = 32, tile_h = 8;
+    bool use_noise = false, stats = false, timings = false;
+    // device memory
+    uint32_t n_slots = 0;
+    Queue q[2]{};
+    ShadowQueue sq{};
+    float4 *hits = nullptr, *Lsum = nullptr, *accum = nullptr, *scratch = nullptr;
+    FrameCounters *ctr = nullptr;
+    Totals *totals = nullptr;
+    void *default_probe = nullptr;
+    void *noise = nullptr;
+    uint32_t noise_w = 0, noise_h = 0;
+    // per-stage timing of the last raytrace()
+    static constexpr int kMaxEvents = 4 * kMaxBounces + 8;
+    hipEvent_t ev_start[kMaxEvents]{}, ev_stop[kMaxEvents]{};
+    int ev_stage[kMaxEvents]{};
+    int n_events = 0;
+    bool events_created = false;
+};
+
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+template <typename T>
+static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
+    const size_t bytes = sizeof(T) * (count ? count : 1);
+    HIP_TRY(hipMalloc(dst, bytes));
+    if (count) HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice, s));
+    return LPT_OK;
+}
+
+extern "C" {
+
+// ============================================================================ Device
+int lpt_device_create(int hip_ordinal, lpt_device **out) {
+    if (!out) return fail(LPT_ERR_INVALID_ARG, "lpt_device_create: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LPT_ERR_HIP, "no HIP device visible (%s); this library has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (hip_ordinal < 0 || hip_ordinal >= n) return fail(LPT_ERR_INVALID_ARG, "HIP ordinal %d out of range (%d devices)", hip_ordinal, n);
+    HIP_TRY(hipSetDevice(hip_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, hip_ordinal));
+    lpt_device *d = new (std::nothrow) lpt_device();
+    if (!d) return fail(LPT_ERR_INVALID_ARG, "out of host memory");
+    d->ordinal = hip_ordinal;
+    d->compute_units = prop.multiProcessorCount;
+    snprintf(d->name, sizeof d->name, "%s (%s)", prop.name, prop.gcnArchName);
+    hipError_t se = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete d; return fail(LPT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
+    *out = d;
+    return LPT_OK;
+}
+
+int lpt_device_destroy(lpt_device *dev) {
+    if (!dev) return LPT_OK;
+    hipSetDevice(dev->ordinal);
+    hipStreamSynchronize(dev->stream);
+    hipStreamDestroy(dev->stream);
+    delete dev;
+    return LPT_OK;
+}
+
+int lpt_device_synchronize(lpt_device *dev) {
+    if (!dev) return fail(LPT_ERR_INVALID_ARG, "lpt_device_synchronize: null");
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return LPT_OK;
+}
+
+int lpt_device_info(lpt_device *dev, char *name, size_t cap, int *cus) {
+    if (!dev) return fail(LPT_ERR_INVALID_ARG, "lpt_device_info: null");
+    if (name && cap) snprintf(name, cap, "%s", dev->name);
+    if (cus) *cus = dev->compute_units;
+    return LPT_OK;
+}
+
+int lpt_device_stream(lpt_device *dev, void **stream) {
+    if (!dev || !stream) return fail(LPT_ERR_INVALID_ARG, "lpt_device_stream: null");
+    *stream = (void *)dev->stream;
+    return LPT_OK;
+}
+
+// ============================================================================ SceneGPU
+int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
+    if (!sg) return LPT_OK;
+    hipSetDevice(sg->dev->ordinal);
+    hipStreamSynchronize(sg->dev->stream);
+    void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->tri_material, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete sg;
+    return LPT_OK;
+}
+
+int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out) {
+    if (!dev || !scene || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload: null");
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    Accel acc;
+    int st = bake_and_build(*scene, acc);
+    if (st != LPT_OK) return st;
+    lpt_scene_gpu *sg = new lpt_scene_gpu();
+    sg->dev = dev;
+    hipStream_t s = dev->stream;
+#define UP(field, vec)                                                         \
+    if ((st = upload(&sg->field, (vec).data(), (vec).size(), s)) != LPT_OK) {  \
+        lpt_scene_gpu_destroy(sg);                                             \
+        return st;                                                             \
+    }
+    UP(nodes, acc.nodes)
+    UP(woop, acc.woop)
+    UP(leaf_prim, acc.leaf_prim)
+    UP(tri_verts, acc.tri_verts)
+    UP(tri_material, acc.tri_material)
+    UP(materials, scene->materials)
+    UP(lights, scene->lights)
+    std::vector<DImage> descs;
+    std::vector<uint8_t> texels;
+    for (const Image &im : scene->images) {
+        DImage di;
+        di.offset = (uint32_t)(texels.size() / 4);
+        di.width = im.width; di.height = im.height; di.pad = 0;
+        descs.push_back(di);
+        texels.insert(texels.end(), im.rgba8.begin(), im.rgba8.end());
+    }
+    UP(images, descs)
+    UP(texels, texels)
+    std::vector<float> lut(256);
+    for (int i = 0; i < 256; ++i) {
+        const double c = (double)i / 255.0;
+        lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    UP(srgb_lut, lut)
+#undef UP
+    hipError_t e = hipStreamSynchronize(s);  // host vectors die at scope exit
+    if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
+    DScene &d = sg->d;
+    d.nodes = (const DNode2 *)sg->nodes;
+    d.woop = (const float4 *)sg->woop;
+    d.leaf_prim = (const uint32_t *)sg->leaf_prim;
+    d.tri_verts = (const float4 *)sg->tri_verts;
+    d.tri_material = (const uint32_t *)sg->tri_material;
+    d.materials = (const lpt_material *)sg->materials;
+    d.lights = (const lpt_light *)sg->lights;
+    d.texels = (const uint8_t *)sg->texels;
+    d.images = (const DImage *)sg->images;
+    d.srgb_lut = (const float *)sg->srgb_lut;
+    d.n_tris = (uint32_t)acc.tri_material.size();
+    d.n_materials = (uint32_t)scene->materials.size();
+    d.n_lights = (uint32_t)scene->lights.size();
+    d.n_images = (uint32_t)scene->images.size();
+    sg->stats.triangles = d.n_tris;
+    sg->stats.nodes = (uint32_t)acc.nodes.size();
+    sg->stats.node_bytes = (uint32_t)sizeof(Node2);
+    sg->stats.tri_bytes = (uint32_t)sizeof(WoopTri);
+    sg->stats.max_depth = acc.max_depth;
+    sg->stats.build_ms = acc.build_ms;
+    *out = sg;
+    return LPT_OK;
+}
+
+int lpt_scene_gpu_stats(const lpt_scene_gpu *sg, lpt_accel_stats *out) {
+    if (!sg || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_stats: null");
+    *out = sg->stats;
+    return LPT_OK;
+}
+
+// ============================================================================ ProbeGPU
+int lpt_probe_upload(lpt_device *dev, const uint8_t *rgbe8, uint32_t w, uint32_t h, lpt_probe **out) {
+    if (!dev || !rgbe8 || !w || !h || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_probe_upload: null or empty");
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    lpt_probe *p = new lpt_probe();
+    p->dev = dev;
+    hipError_t e = hipMalloc(&p->rgbe, (size_t)w * h * 4);
+    if (e == hipSuccess) e = hipMemcpy(p->rgbe, rgbe8, (size_t)w * h * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (p->rgbe) hipFree(p->rgbe); delete p; return fail(LPT_ERR_HIP, "probe upload failed: %s", hipGetErrorString(e)); }
+    p->d.rgbe = (const uint8_t *)p->rgbe;
+    p->d.w = w; p->d.h = h;
+    *out = p;
+    return LPT_OK;
+}
+
+int lpt_probe_destroy(lpt_probe *p) {
+    if (!p) return LPT_OK;
+    hipSetDevice(p->dev->ordinal);
+    hipStreamSynchronize(p->dev->stream);
+    if (p->rgbe) hipFree(p->rgbe);
+    delete p;
+    return LPT_OK;
+}
+
+// ============================================================================ ray queries
+int lpt_trace_closest(lpt_device *dev, const lpt_scene_gpu *sg, const float *origins, const float *dirs, uint32_t n, lpt_hit *out) {
+    if (!dev || !sg || (n && (!origins || !dirs || !out))) return fail(LPT_ERR_INVALID_ARG, "lpt_trace_closest: null");
+    if (!n) return LPT_OK;
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    std::vector<float4> o(n), d(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+        d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], -1.f);
+    }
+    float4 *dO = nullptr, *dD = nullptr, *dH = nullptr;
+    FrameCounters *ctr = nullptr;
+    int st = LPT_OK;
+    hipError_t e = hipMalloc(&dO, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc(&dD, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc(&dH, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc(&ctr, sizeof(FrameCounters));
+    if (e == hipSuccess) e = hipMemcpyAsync(dO, o.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dD, d.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(FrameCounters), dev->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&ctr->qcount[0], &n, sizeof n, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) {
+        Queue q{dO, dD, nullptr};
+        const uint32_t blocks = std::min<uint32_t>(div_up(n, kBlock), (uint32_t)dev->compute_units * 4u);
+        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), 0, dev->stream, sg->d, q, dH, ctr, 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dH, sizeof(float4) * n, hipMemcpyDeviceToHost, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) st = fail(LPT_ERR_HIP, "lpt_trace_closest: %s", hipGetErrorString(e));
+    hipFree(dO); hipFree(dD); hipFree(dH); hipFree(ctr);
+    return st;
+}
+
+int lpt_trace_occluded(lpt_device *dev, const lpt_scene_gpu *sg, const float *origins, const float *dirs, const float *tmax, uint32_t n, uint8_t *out) {
+    if (!dev || !sg || (n && (!origins || !dirs || !tmax || !out))) return fail(LPT_ERR_INVALID_ARG, "lpt_trace_occluded: null");
+    if (!n) return LPT_OK;
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    std::vector<float4> o(n), d(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tmax[i]);
+        d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.f);
+    }
+    float4 *dO = nullptr, *dD = nullptr;
+    uint8_t *dR = nullptr;
+    int st = LPT_OK;
+    hipError_t e = hipMalloc(&dO, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc(&dD, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMalloc(&dR, n);
+    if (e == hipSuccess) e = hipMemcpyAsync(dO, o.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dD, d.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_query_occluded, dim3(div_up(n, kBlock)), dim3(kBlock), 0, dev->stream, sg->d, dO, dD, dR, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dR, n, hipMemcpyDeviceToHost, dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+    if (e != hipSuccess) st = fail(LPT_ERR_HIP, "lpt_trace_occluded: %s", hipGetErrorString(e));
+    hipFree(dO); hipFree(dD); hipFree(dR);
+    return st;
+}
+
+// ============================================================================ Renderer
+static void free_frame_buffers(lpt_renderer *r) {
+    void *ptrs[] = {r->q[0].o, r->q[0].d, r->q[0].T, r->q[1].o, r->q[1].d, r->q[1].T, r->sq.o, r->sq.d, r->sq.c, r->hits, r->Lsum, r->accum, r->scratch};
+    for (void *p : ptrs) if (p) hipFree(p);
+    r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
+    r->hits = r->Lsum = r->accum = r->scratch = nullptr;
+    r->n_slots = 0;
+}
+
+static void shard_geometry(const lpt_renderer *r, uint32_t &tiles_x, uint32_t &n_tiles, uint32_t &n_slots) {
+    tiles_x = div_up(r->w, r->tile_w);
+    const uint32_t tiles_y = div_up(r->h, r->tile_h);
+    n_tiles = tiles_x * tiles_y;
+    const uint32_t owned = n_tiles > r->rank ? div_up(n_tiles - r->rank, r->world) : 0u;
+    n_slots = owned * r->tile_w * r->tile_h;
+}
+
+static int alloc_frame_buffers(lpt_renderer *r) {
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    free_frame_buffers(r);
+    if (!r->w || !r->h) return LPT_OK;
+    uint32_t tiles_x, n_tiles, n_slots;
+    shard_geometry(r, tiles_x, n_tiles, n_slots);
+    const size_t n = n_slots ? n_slots : 64;
+    const size_t px = (size_t)r->w * r->h;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&r->q[k].o, sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&r->q[k].d, sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&r->q[k].T, sizeof(float4) * n));
+    }
+    HIP_TRY(hipMalloc(&r->sq.o, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->sq.d, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->sq.c, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->hits, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->Lsum, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->accum, sizeof(float4) * px));
+    HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
+    HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->dev->stream));
+    r->n_slots = n_slots;
+    return LPT_OK;
+}
+
+int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_renderer **out) {
+    if (!dev || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_create: null");
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    lpt_renderer *r = new lpt_renderer();
+    r->dev = dev;
+    r->req_w = width; r->req_h = height;
+    // get_downsampled_size (renderer.rs:18-22)
+    r->w = (uint32_t)((float)width * r->downsample);
+    r->h = (uint32_t)((float)height * r->downsample);
+    hipError_t e = hipMalloc(&r->ctr, sizeof(FrameCounters));
+    if (e == hipSuccess) e = hipMalloc(&r->totals, sizeof(Totals));
+    if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
+    if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
+    if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
+    if (e != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e)); }
+    int st = alloc_frame_buffers(r);
+    if (st != LPT_OK) { lpt_renderer_destroy(r); return st; }
+    *out = r;
+    return LPT_OK;
+}
+
+int lpt_renderer_destroy(lpt_renderer *r) {
+    if (!r) return LPT_OK;
+    hipSetDevice(r->dev->ordinal);
+    hipStreamSynchronize(r->dev->stream);
+    free_frame_buffers(r);
+    if (r->ctr) hipFree(r->ctr);
+    if (r->totals) hipFree(r->totals);
+    if (r->default_probe) hipFree(r->default_probe);
+    if (r->noise) hipFree(r->noise);
+    if (r->events_created)
+        for (int i = 0; i < lpt_renderer::kMaxEvents; ++i) { hipEventDestroy(r->ev_start[i]); hipEventDestroy(r->ev_stop[i]); }
+    delete r;
+    return LPT_OK;
+}
+
+int lpt_renderer_set_downsample(lpt_renderer *r, float factor) {
+    if (!r || !(factor > 0.f) || factor > 16.f) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_downsample: factor must be in (0,16]");
+    r->downsample = factor;
+    return LPT_OK;
+}
+
+int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe) {
+    if (!r || !sg) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_resources: null");
+    if (sg->dev != r->dev || (probe && probe->dev != r->dev)) return fail(LPT_ERR_INVALID_ARG, "resources belong to another device");
+    r->sg = sg;
+    r->probe = probe;
+    r->resources_set = true;
+    r->frame_count = 1;  // renderer.rs:724
+    return LPT_OK;
+}
+
+int lpt_renderer_resize(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe, uint32_t width, uint32_t height) {
+    if (!r || !sg) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_resize: null");
+    r->req_w = width; r->req_h = height;
+    r->w = (uint32_t)((float)width * r->downsample);
+    r->h = (uint32_t)((float)height * r->downsample);
+    int st = alloc_frame_buffers(r);
+    if (st != LPT_OK) return st;
+    return lpt_renderer_set_resources(r, sg, probe);
+}
+
+int lpt_renderer_get_size(const lpt_renderer *r, uint32_t *w, uint32_t *h) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_size: null");
+    if (w) *w = r->w;
+    if (h) *h = r->h;
+    return LPT_OK;
+}
+
+// largest per-pixel record: a queued ray (origin+slot, dir+pdf, throughput) = 48 B
+uint32_t lpt_max_per_pixel_bytes(void) { return 48u; }
+
+int lpt_renderer_set_max_bounces(lpt_renderer *r, uint32_t b) {
+    if (!r || b == 0 || b > (uint32_t)kMaxBounces) return fail(LPT_ERR_INVALID_ARG, "max_bounces must be in [1,%d]", kMaxBounces);
+    r->max_bounces = b;
+    return LPT_OK;
+}
+int lpt_renderer_set_seed(lpt_renderer *r, uint32_t s) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_seed: null");
+    r->user_seed = s;
+    return LPT_OK;
+}
+int lpt_renderer_set_vfov(lpt_renderer *r, float radians) {
+    if (!r || !(radians > 0.f) || !(radians < 3.14159f)) return fail(LPT_ERR_INVALID_ARG, "vfov must be in (0, pi)");
+    r->vfov = radians;
+    return LPT_OK;
+}
+int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h) {
+    if (!r || world == 0 || rank >= world || tile_w == 0 || tile_h == 0 || (tile_w * tile_h) % 64u != 0u)
+        return fail(LPT_ERR_INVALID_ARG, "bad shard (rank %u of %u, tile %ux%u; tile area must be a multiple of 64)", rank, world, tile_w, tile_h);
+    r->rank = rank; r->world = world; r->tile_w = tile_w; r->tile_h = tile_h;
+    r->frame_count = 1;
+    return alloc_frame_buffers(r);
+}
+int lpt_renderer_reset_accumulation(lpt_renderer *r) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_reset_accumulation: null");
+    r->frame_count = 1;       // renderer.rs:610
+    r->accumulate = false;    // :611 ; the seed is deliberately not reset (:613-615)
+    return LPT_OK;
+}
+int lpt_renderer_set_accumulate(lpt_renderer *r, int a) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_accumulate: null");
+    r->accumulate = a != 0;
+    return LPT_OK;
+}
+int lpt_renderer_get_accumulate(const lpt_renderer *r, int *a) {
+    if (!r || !a) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_accumulate: null");
+    *a = r->accumulate ? 1 : 0;
+    return LPT_OK;
+}
+int lpt_renderer_get_frame_state(const lpt_renderer *r, uint32_t *fc, uint32_t *seed) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_frame_state: null");
+    if (fc) *fc = r->frame_count;
+    if (seed) *seed = r->seed;
+    return LPT_OK;
+}
+int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t w, uint32_t h, uint32_t row_bytes) {
+    if (!r || !rgba8 || !w || !h || row_bytes < w * 4u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_upload_noise: bad arguments");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    if (r->noise) { hipFree(r->noise); r->noise = nullptr; }
+    HIP_TRY(hipMalloc(&r->noise, (size_t)w * h * 4));
+    HIP_TRY(hipMemcpy2D(r->noise, (size_t)w * 4, rgba8, row_bytes, (size_t)w * 4, h, hipMemcpyHostToDevice));
+    r->noise_w = w; r->noise_h = h;
+    return LPT_OK;
+}
+int lpt_renderer_use_noise(lpt_renderer *r, int flag) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_use_noise: null");
+    r->use_noise = flag != 0;
+    return LPT_OK;
+}
+int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode) {
+    if (!r || mode < LPT_BLIT_PATHTRACE || mode > LPT_BLIT_MOTION) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_blit_mode: bad mode %d", mode);
+    r->mode = mode;
+    return LPT_OK;
+}
+int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_stats: null");
+    r->stats = flag != 0;
+    return LPT_OK;
+}
+int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_timings: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    if (flag && !r->events_created) {
+        for (int i = 0; i < lpt_renderer::kMaxEvents; ++i) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
+        r->events_created = true;
+    }
+    r->timings = flag != 0;
+    r->n_events = 0;
+    return LPT_OK;
+}
+
+static inline void stage_begin(lpt_renderer *r, int stage) {
+    if (!r->timings || r->n_events >= lpt_renderer::kMaxEvents) return;
+    r->ev_stage[r->n_events] = stage;
+    hipEventRecord(r->ev_start[r->n_events], r->dev->stream);
+}
+static inline void stage_end(lpt_renderer *r) {
+    if (!r->timings || r->n_events >= lpt_renderer::kMaxEvents) return;
+    hipEventRecord(r->ev_stop[r->n_events], r->dev->stream);
+    r->n_events++;
+}
+
+int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
+    if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
+    r->frame_back = !r->frame_back;              // renderer.rs:401
+    if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
+    if (!r->w || !r->h) return LPT_OK;
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    hipStream_t s = r->dev->stream;
+    const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
+
+    FrameParams p;
+    p.right = mk3(view[0], view[1], view[2]);    // camera.rs:101-108: cols = right, up, direction, origin
+    p.up = mk3(view[4], view[5], view[6]);
+    p.fwd = mk3(view[8], view[9], view[10]);
+    p.origin = mk3(view[12], view[13], view[14]);
+    const float th = tanf(0.5f * r->vfov);
+    const float aspect = (float)r->w / (float)r->h;
+    p.ax = aspect * th; p.ay = th;
+    p.width = r->w; p.height = r->h;             // camera.dimensions / global_uniforms.dimensions (:431,436)
+    p.user_seed = r->user_seed;
+    p.seed_counter = r->seed;
+    p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
+    shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
+    p.frame_count = r->frame_count;
+    p.max_bounces = nb;
+
+    DProbe probe = r->probe ? r->probe->d : DProbe{(const uint8_t *)r->default_probe, 1u, 1u};
+    DNoise nz{(const uint8_t *)r->noise, r->noise_w, r->noise_h, (r->use_noise && r->noise) ? 1u : 0u};
+    const DScene &sc = r->sg->d;
+    r->n_events = 0;
+
+    if (p.n_slots) {
+        HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
+        const uint32_t cus = (uint32_t)r->dev->compute_units;
+        const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 8u);
+        const uint32_t trace_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 4u);
+
+        // "ray generation" (:444-448)
+        stage_begin(r, ST_RAYGEN);
+        hipLaunchKernelGGL(k_raygen, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+        stage_end(r);
+
+        uint32_t seed = r->seed;
+        for (uint32_t b = 0; b < nb; ++b) {
+            seed += 1u;                          // :453, :487
+            const Queue qin = r->q[b & 1u], qout = r->q[(b + 1u) & 1u];
+            stage_begin(r, ST_INTERSECT);        // :457-464, :493-498
+            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, qin, r->hits, r->ctr, (int)b);
+            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, qin, r->hits, r->ctr, (int)b);
+            stage_end(r);
+            stage_begin(r, ST_SHADE);            // :471-480, :502-508
+            hipLaunchKernelGGL(k_shade, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed);
+            stage_end(r);
+            stage_begin(r, ST_SHADOW);
+            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
+            stage_end(r);
+        }
+        if (r->mode == LPT_BLIT_PATHTRACE || true) {
+            // AccumulationPass (:523-538).  The denoiser modes are not built yet; every mode accumulates.
+            stage_begin(r, ST_ACCUM);
+            hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->accum);
+            stage_end(r);
+        }
+        hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, s, r->ctr, r->totals, nb);
+        HIP_TRY(hipGetLastError());
+    }
+    r->seed += nb;                               // seed += 1 per intersect stage, never reset
+    if (r->accumulate) r->frame_count += 1u;     // :535-537
+    return LPT_OK;
+}
+
+int lpt_renderer_synchronize(lpt_renderer *r) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_synchronize: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    return LPT_OK;
+}
+
+int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes) {
+    if (!r || !ptr) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_radiance_device_ptr: null");
+    *ptr = r->accum;
+    if (bytes) *bytes = sizeof(float4) * (size_t)r->w * r->h;
+    return LPT_OK;
+}
+
+int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
+    if (!r || !dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance: null");
+    if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
+    hipError_t e = hipSetDevice(r->dev->ordinal);
+    const uint32_t n = r->w * r->h;
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_resolve, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, r->scratch, n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->dev->stream);
+    if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
+    return LPT_OK;
+}
+
+int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
+    if (!r || !dst || row_bytes < (size_t)r->w * 4) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_blit_rgba8: bad arguments");
+    if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
+    hipError_t e = hipSetDevice(r->dev->ordinal);
+    const uint32_t n = r->w * r->h;
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, (uchar4 *)r->scratch, n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->dev->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->dev->stream);
+    if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
+    return LPT_OK;
+}
+
+int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst) {
+    if (!r || !dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_pixels: null");
+    return lpt_renderer_blit_rgba8(r, dst, (size_t)r->w * 4);
+}
+
+int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
+    if (!r || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_ray_counts: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    Totals t;
+    HIP_TRY(hipMemcpyAsync(&t, r->totals, sizeof t, hipMemcpyDeviceToHost, r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    out->closest = t.closest; out->shadow = t.shadow; out->shaded = t.shaded; out->nodes = t.nodes; out->tris = t.tris;
+    return LPT_OK;
+}
+
+int lpt_renderer_reset_ray_counts(lpt_renderer *r) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_reset_ray_counts: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipMemsetAsync(r->totals, 0, sizeof(Totals), r->dev->stream));
+    return LPT_OK;
+}
+
+int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count) {
+    if (!r || !inout_count) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_timings: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    lpt_timing acc[ST_COUNT];
+    for (int i = 0; i < ST_COUNT; ++i) { memset(&acc[i], 0, sizeof acc[i]); snprintf(acc[i].label, sizeof acc[i].label, "%s", kStageLabel[i]); }
+    for (int i = 0; i < r->n_events; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r->ev_start[i], r->ev_stop[i]) == hipSuccess) { acc[r->ev_stage[i]].ms += ms; acc[r->ev_stage[i]].launches++; }
+    }
+    const int n = std::min(*inout_count, (int)ST_COUNT);
+    if (out) for (int i = 0; i < n; ++i) out[i] = acc[i];
+    *inout_count = ST_COUNT;
+    return LPT_OK;
+}
+
+}  // extern "C"

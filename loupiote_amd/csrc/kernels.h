@@ -1,0 +1,578 @@
+// kernels.h — the wavefront path-tracing kernels for gfx950 (included by device.hip).
+//
+// Stage kernels, one per pass the reference records in Renderer::raytrace
+// (reference crates/lib/src/renderer.rs:444-538):
+//   k_raygen      <- passes::RayPass           (:444-448)
+//   k_intersect   <- passes::IntersectorPass   (:458-463, :493-498)
+//   k_shade       <- passes::PrimaryRayPass / passes::ShadingPass (:472-479, :502-508)
+//   k_shadow      <- the shadow rays the reference's shading pass traces inline
+//   k_accumulate  <- passes::AccumulationPass  (:525-533)
+// Unlike the reference (full pixel grid per dispatch, one ray slot per pixel) live
+// paths are stream-compacted into a queue after every bounce with a wave64
+// ballot + popcount prefix and ONE atomic per wave, and the traversal kernels are
+// persistent: a fixed grid of waves pulls 64-ray packets from a device-side head.
+#pragma once
+#include "device_math.h"
+
+namespace lptd {
+
+constexpr int kMaxBounces = 64;
+constexpr int kStackSize = 32;  // >= bvh.cpp kMaxDepth + 2
+constexpr int kBlock = 256;
+
+struct DNode2 {  // 64 B, mirrors lpt::Node2
+    float4 a;    // lo0.xyz, hi0.x
+    float4 b;    // hi0.yz, lo1.xy
+    float4 c;    // lo1.z, hi1.xyz
+    int child0, child1, pad0, pad1;
+};
+
+struct DImage { uint32_t offset, width, height, pad; };
+
+struct DScene {
+    const DNode2 *nodes;
+    const float4 *woop;          // 3 per leaf slot
+    const uint32_t *leaf_prim;   // leaf slot -> baked triangle id
+    const float4 *tri_verts;     // 6 per baked triangle: (pos,u)(nrm,v) x3
+    const uint32_t *tri_material;
+    const lpt_material *materials;
+    const lpt_light *lights;
+    const uint8_t *texels;       // RGBA8, all images back to back
+    const DImage *images;
+    const float *srgb_lut;       // 256 entries
+    uint32_t n_tris, n_materials, n_lights, n_images;
+};
+
+struct DProbe { const uint8_t *rgbe; uint32_t w, h; };
+struct DNoise { const uint8_t *rgba; uint32_t w, h, enabled; };
+
+struct Queue { float4 *o; float4 *d; float4 *T; };          // o.w = pixel slot bits, d.w = pdf of the sampling bounce (<0: camera)
+struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w = pixel slot bits, c = contribution
+
+struct FrameCounters {
+    uint32_t qcount[kMaxBounces + 1];
+    uint32_t shcount[kMaxBounces];
+    uint32_t ihead[kMaxBounces];
+    uint32_t shead[kMaxBounces];
+    uint32_t shaded[kMaxBounces];
+    unsigned long long nodes, tris;
+};
+struct Totals { unsigned long long closest, shadow, shaded, nodes, tris; };
+
+struct FrameParams {
+    f3 origin, right, up, fwd;
+    float ax, ay;
+    uint32_t width, height;
+    uint32_t user_seed, seed_counter;
+    uint32_t rank, world, tile_w, tile_h, tiles_x, n_tiles, n_slots;
+    uint32_t frame_count, max_bounces;
+};
+
+// pixel slot -> pixel.  Slots enumerate this rank's tiles (tile ids rank, rank+world, ...)
+// and the pixels inside each tile row-major, so a wave64 covers a 32x2 pixel block.
+__device__ __forceinline__ bool slot_to_pixel(const FrameParams &p, uint32_t slot, uint32_t &x, uint32_t &y) {
+    const uint32_t per_tile = p.tile_w * p.tile_h;
+    const uint32_t k = slot / per_tile, within = slot - k * per_tile;
+    const uint32_t tile = p.rank + k * p.world;
+    if (tile >= p.n_tiles) return false;
+    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const uint32_t wy = within / p.tile_w, wx = within - wy * p.tile_w;
+    x = tx * p.tile_w + wx;
+    y = ty * p.tile_h + wy;
+    return x < p.width && y < p.height;
+}
+
+// wave64 stream compaction: returns this lane's output index (valid lanes only)
+__device__ __forceinline__ uint32_t wave_compact(bool valid, uint32_t *counter) {
+    const unsigned long long mask = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void noise_shift(const DNoise &nz, uint32_t x, uint32_t y, uint32_t seed_counter, float &r0, float &r1) {
+    if (!nz.enabled) return;
+    const uint8_t *t = nz.rgba + 4u * ((size_t)(y % nz.h) * nz.w + (x % nz.w));
+    float g = (float)(seed_counter & 1023u) * 0.61803398875f;
+    float a = r0 + ((float)t[0] + 0.5f) * 0.00390625f + g;
+    float b = r1 + ((float)t[1] + 0.5f) * 0.00390625f + g;
+    a = a - floorf(a);
+    b = b - floorf(b);
+    if (a >= 1.0f) a = 0.0f;
+    if (b >= 1.0f) b = 0.0f;
+    r0 = a;
+    r1 = b;
+}
+
+// ------------------------------------------------------------------ ray generation
+__global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Queue q, float4 *Lsum, FrameCounters *ctr) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // n_slots is a multiple of 64 (tile_w*tile_h is), so whole waves stay converged for the ballot
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x = 0, y = 0;
+        const bool valid = slot_to_pixel(p, slot, x, y);
+        Lsum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f3 d = mk3(0.f, 0.f, 0.f);
+        if (valid) {
+            const uint32_t pixel = y * p.width + x;
+            Rng r = rng_init(pixel, stage_seed(p.user_seed, p.seed_counter), LPT_TAG_RAYGEN);
+            float jx = rng_next(r), jy = rng_next(r);
+            noise_shift(nz, x, y, p.seed_counter, jx, jy);
+            float sx = ((float)x + jx) / (float)p.width;
+            float sy = ((float)y + jy) / (float)p.height;
+            float cx = (2.0f * sx - 1.0f) * p.ax;
+            float cy = (1.0f - 2.0f * sy) * p.ay;
+            f3 dir = mk3((p.right.x * cx + p.up.x * cy) + p.fwd.x, (p.right.y * cx + p.up.y * cy) + p.fwd.y,
+                         (p.right.z * cx + p.up.z * cy) + p.fwd.z);
+            d = normalize(dir);
+        }
+        const uint32_t idx = wave_compact(valid, &ctr->qcount[0]);
+        if (valid) {
+            q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(slot));
+            q.d[idx] = make_float4(d.x, d.y, d.z, -1.0f);
+            q.T[idx] = make_float4(1.f, 1.f, 1.f, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ traversal
+struct Hit { float t, u, v; uint32_t prim; };
+
+// SPEC §7 Woop test; accepts tmin(0) < t <= tmax, caller applies the tie rule
+__device__ __forceinline__ bool ray_triangle(const float4 r0, const float4 r1, const float4 r2, f3 o, f3 d, float tmax, float &t, float &u, float &v) {
+    float oz = fmaf(r2.z, o.z, fmaf(r2.y, o.y, fmaf(r2.x, o.x, r2.w)));
+    float dz = fmaf(r2.z, d.z, fmaf(r2.y, d.y, r2.x * d.x));
+    float tt = -oz / dz;
+    if (!(tt > 0.0f && tt <= tmax)) return false;
+    float ox = fmaf(r0.z, o.z, fmaf(r0.y, o.y, fmaf(r0.x, o.x, r0.w)));
+    float dx = fmaf(r0.z, d.z, fmaf(r0.y, d.y, r0.x * d.x));
+    float uu = fmaf(tt, dx, ox);
+    if (!(uu >= 0.0f)) return false;
+    float oy = fmaf(r1.z, o.z, fmaf(r1.y, o.y, fmaf(r1.x, o.x, r1.w)));
+    float dy = fmaf(r1.z, d.z, fmaf(r1.y, d.y, r1.x * d.x));
+    float vv = fmaf(tt, dy, oy);
+    if (!(vv >= 0.0f) || !(uu + vv <= 1.0f)) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+__device__ __forceinline__ float safe_inv(float d) {
+    // a zero component must not produce 0*inf = NaN in the slab test
+    return fabsf(d) > 1.0e-30f ? 1.0f / d : copysignf(1.0e30f, d);
+}
+
+// Conservative slab test: [tn,tf] widened by a few ulp.  Box-vs-oracle agreement is not
+// required (only conservativeness); the triangle test decides the result.
+__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, float tbest, float &tn) {
+    float t0x = (lx - o.x) * inv.x, t1x = (hx - o.x) * inv.x;
+    float t0y = (ly - o.y) * inv.y, t1y = (hy - o.y) * inv.y;
+    float t0z = (lz - o.z) * inv.z, t1z = (hz - o.z) * inv.z;
+    float nx = fminf(t0x, t1x), fx = fmaxf(t0x, t1x);
+    float ny = fminf(t0y, t1y), fy = fmaxf(t0y, t1y);
+    float nz = fminf(t0z, t1z), fz = fmaxf(t0z, t1z);
+    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f)) * 0.9999996f;
+    float tf = fminf(fminf(fx, fy), fz) * 1.0000004f;
+    tf = fminf(tf, tbest);
+    return tn <= tf;
+}
+
+// One ray against the baked BVH.  ANY: stop at the first hit in (0, tmax].
+// `stack` points at this thread's column of the block's LDS stack (stride kBlock ints).
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool traverse(const DScene &sc, f3 o, f3 d, float tmax, int *stack, Hit &best, uint32_t &n_nodes, uint32_t &n_tris) {
+    best.t = tmax; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;
+    const f3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    int sp = 0;
+    int cur = 0;  // root
+    for (;;) {
+        if (cur >= 0) {
+            const DNode2 *n = sc.nodes + cur;
+            const float4 a = n->a, b = n->b, c = n->c;
+            const int c0 = n->child0, c1 = n->child1;
+            if (STATS) n_nodes++;
+            float tn0, tn1;
+            const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, best.t, tn0);
+            const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, best.t, tn1);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                stack[sp * kBlock] = farc;
+                sp++;
+                cur = nearc;
+                continue;
+            }
+            if (h0) { cur = c0; continue; }
+            if (h1) { cur = c1; continue; }
+        } else {
+            const uint32_t ref = (uint32_t)(~cur);
+            const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4 *w = sc.woop + 3u * (size_t)(first + i);
+                const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+                if (STATS) n_tris++;
+                float t, u, v;
+                if (ray_triangle(r0, r1, r2, o, d, best.t, t, u, v)) {
+                    if (ANY) return true;
+                    const uint32_t prim = sc.leaf_prim[first + i];
+                    if (t < best.t || prim < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * kBlock];
+    }
+    return best.prim != 0xFFFFFFFFu;
+}
+
+// SPEC §8: rectangular emitters (front face only, strictly closer than any triangle)
+__device__ __forceinline__ void intersect_lights(const DScene &sc, f3 o, f3 d, Hit &best) {
+    for (uint32_t l = 0; l < sc.n_lights; ++l) {
+        const float4 *L = reinterpret_cast<const float4 *>(sc.lights + l);
+        const float4 n4 = L[0], t4 = L[1], b4 = L[2], o4 = L[3];
+        const f3 nl = mk3(n4.x, n4.y, n4.z);
+        float dn = dot(d, nl);
+        if (!(dn < 0.0f)) continue;
+        const f3 ctr = mk3(o4.x, o4.y, o4.z);
+        float t = dot(ctr - o, nl) / dn;
+        if (!(t > 0.0f && t < best.t)) continue;
+        f3 p = mk3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+        f3 r = p - ctr;
+        float a = dot(r, mk3(t4.x, t4.y, t4.z));
+        float b = dot(r, mk3(b4.x, b4.y, b4.z));
+        if (fabsf(a) <= t4.w && fabsf(b) <= b4.w) { best.t = t; best.u = a; best.v = b; best.prim = LPT_LIGHT_BIT | l; }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
+    __shared__ int lds_stack[kStackSize * kBlock];
+    int *stack = lds_stack + threadIdx.x;
+    const uint32_t count = ctr->qcount[bounce];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->ihead[bounce], 64u);
+        base = __shfl(base, 0);
+        if (base >= count) break;
+        const uint32_t i = base + lane;
+        if (i < count) {
+            const float4 o4 = q.o[i], d4 = q.d[i];
+            const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+            Hit h;
+            traverse<false, STATS>(sc, o, d, LPT_T_INF, stack, h, n_nodes, n_tris);
+            intersect_lights(sc, o, d, h);
+            hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        }
+    }
+    if (STATS) {
+        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce) {
+    __shared__ int lds_stack[kStackSize * kBlock];
+    int *stack = lds_stack + threadIdx.x;
+    const uint32_t count = ctr->shcount[bounce];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->shead[bounce], 64u);
+        base = __shfl(base, 0);
+        if (base >= count) break;
+        const uint32_t i = base + lane;
+        if (i < count) {
+            const float4 o4 = sq.o[i], d4 = sq.d[i];
+            Hit h;
+            const bool occluded = traverse<true, STATS>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, n_nodes, n_tris);
+            if (!occluded) {
+                const uint32_t slot = __float_as_uint(d4.w);
+                const float4 c = sq.c[i];
+                float4 L = Lsum[slot];
+                L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+                Lsum[slot] = L;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+    }
+}
+
+// ------------------------------------------------------------------ SPEC §9 textures / environment
+__device__ __forceinline__ int wrap_i(int x, int n) { int m = x % n; return m < 0 ? m + n : m; }
+
+__device__ __forceinline__ float4 texture_lookup(const DScene &sc, uint32_t image, float u, float v, bool srgb) {
+    const DImage im = sc.images[image];
+    const int W = (int)im.width, H = (int)im.height;
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    int x0 = wrap_i((int)x0f, W), x1 = wrap_i((int)x0f + 1, W);
+    int y0 = wrap_i((int)y0f, H), y1 = wrap_i((int)y0f + 1, H);
+    const uchar4 *base = reinterpret_cast<const uchar4 *>(sc.texels) + im.offset;
+    const uchar4 p00 = base[(size_t)y0 * W + x0], p10 = base[(size_t)y0 * W + x1];
+    const uchar4 p01 = base[(size_t)y1 * W + x0], p11 = base[(size_t)y1 * W + x1];
+    const uint8_t a00[4] = {p00.x, p00.y, p00.z, p00.w}, a10[4] = {p10.x, p10.y, p10.z, p10.w};
+    const uint8_t a01[4] = {p01.x, p01.y, p01.z, p01.w}, a11[4] = {p11.x, p11.y, p11.z, p11.w};
+    float out[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        float c00, c10, c01, c11;
+        if (srgb && ch < 3) { c00 = sc.srgb_lut[a00[ch]]; c10 = sc.srgb_lut[a10[ch]]; c01 = sc.srgb_lut[a01[ch]]; c11 = sc.srgb_lut[a11[ch]]; }
+        else {
+            c00 = (float)a00[ch] * 0.003921568859368563f; c10 = (float)a10[ch] * 0.003921568859368563f;
+            c01 = (float)a01[ch] * 0.003921568859368563f; c11 = (float)a11[ch] * 0.003921568859368563f;
+        }
+        float top = c00 * (1.0f - tx) + c10 * tx, bot = c01 * (1.0f - tx) + c11 * tx;
+        out[ch] = top * (1.0f - ty) + bot * ty;
+    }
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
+__device__ __forceinline__ f3 rgbe_decode(uchar4 p) {
+    const uint32_t e = p.w;
+    float scale = 0.0f;
+    if (e >= 10u) scale = __uint_as_float((e - 9u) << 23);  // 2^(e-136)
+    return mk3((float)p.x * scale, (float)p.y * scale, (float)p.z * scale);
+}
+
+__device__ __forceinline__ f3 env_lookup(const DProbe &pr, f3 d) {
+    const int W = (int)pr.w, H = (int)pr.h;
+    const uchar4 *tex = reinterpret_cast<const uchar4 *>(pr.rgbe);
+    if (W == 1 && H == 1) return rgbe_decode(tex[0]);
+    float phi = atan2_approx(d.z, d.x);
+    float u = phi * LPT_INV_2PI + 0.5f;
+    float th = acos_approx(clampf(d.y, -1.0f, 1.0f));
+    float v = th * LPT_INV_PI;
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    int x0 = wrap_i((int)x0f, W), x1 = wrap_i((int)x0f + 1, W);
+    int y0 = (int)y0f, y1 = (int)y0f + 1;
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    const f3 c00 = rgbe_decode(tex[(size_t)y0 * W + x0]), c10 = rgbe_decode(tex[(size_t)y0 * W + x1]);
+    const f3 c01 = rgbe_decode(tex[(size_t)y1 * W + x0]), c11 = rgbe_decode(tex[(size_t)y1 * W + x1]);
+    f3 r;
+    { float top = c00.x * (1.0f - tx) + c10.x * tx, bot = c01.x * (1.0f - tx) + c11.x * tx; r.x = top * (1.0f - ty) + bot * ty; }
+    { float top = c00.y * (1.0f - tx) + c10.y * tx, bot = c01.y * (1.0f - tx) + c11.y * tx; r.y = top * (1.0f - ty) + bot * ty; }
+    { float top = c00.z * (1.0f - tx) + c10.z * tx, bot = c01.z * (1.0f - tx) + c11.z * tx; r.z = top * (1.0f - ty) + bot * ty; }
+    return r;
+}
+
+// ------------------------------------------------------------------ shading (SPEC §12)
+__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
+                                                  Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
+                                                  uint32_t seed_counter) {
+    const uint32_t count = ctr->qcount[bounce];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounded = (count + 63u) & ~63u;  // keep whole waves in the loop for the ballots
+    const bool last_bounce = (uint32_t)bounce + 1u >= p.max_bounces;
+    const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
+        bool want_next = false, want_shadow = false, is_surface = false;
+        float4 no4, nd4, nT4, so4, sd4, sc4;
+        if (i < count) {
+            const float4 o4 = qin.o[i], d4 = qin.d[i], T4 = qin.T[i], h4 = hits[i];
+            const uint32_t slot = __float_as_uint(o4.w);
+            const f3 d = mk3(d4.x, d4.y, d4.z);
+            const f3 T = mk3(T4.x, T4.y, T4.z);
+            const float pdf_prev = d4.w;
+            const uint32_t prim = __float_as_uint(h4.w);
+            if (prim == 0xFFFFFFFFu) {
+                const f3 e = env_lookup(probe, d);
+                float4 L = Lsum[slot];
+                L.x = L.x + T.x * e.x; L.y = L.y + T.y * e.y; L.z = L.z + T.z * e.z;
+                Lsum[slot] = L;
+            } else if (prim & LPT_LIGHT_BIT) {
+                const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + (prim & ~LPT_LIGHT_BIT));
+                const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
+                const float Le = lo4.w;
+                float w = 1.0f;
+                if (pdf_prev >= 0.0f) {
+                    float cl = -dot(mk3(n4.x, n4.y, n4.z), d);
+                    float area = 4.0f * (t4.w * b4.w);
+                    float pl = ((h4.x * h4.x) / (cl * area)) * inv_nl;
+                    float pb2 = pdf_prev * pdf_prev;
+                    w = pb2 / (pb2 + pl * pl);
+                }
+                float k = Le * w;
+                float4 L = Lsum[slot];
+                L.x = L.x + T.x * k; L.y = L.y + T.y * k; L.z = L.z + T.z * k;
+                Lsum[slot] = L;
+            } else {
+                const float hu = h4.y, hv = h4.z;
+                const float4 *tv = sc.tri_verts + 6u * (size_t)prim;
+                const float4 P0 = tv[0], N0 = tv[1], P1 = tv[2], N1 = tv[3], P2 = tv[4], N2 = tv[5];
+                float bw = (1.0f - hu) - hv;
+                const f3 p0 = mk3(P0.x, P0.y, P0.z), p1 = mk3(P1.x, P1.y, P1.z), p2 = mk3(P2.x, P2.y, P2.z);
+                f3 P = mk3((p0.x * bw + p1.x * hu) + p2.x * hv, (p0.y * bw + p1.y * hu) + p2.y * hv, (p0.z * bw + p1.z * hu) + p2.z * hv);
+                f3 Ng = cross(p1 - p0, p2 - p0);
+                float l2 = dot(Ng, Ng);
+                if (l2 > 0.0f) {
+                    is_surface = true;
+                    Ng = Ng * (1.0f / sqrtf(l2));
+                    f3 Ns = mk3((N0.x * bw + N1.x * hu) + N2.x * hv, (N0.y * bw + N1.y * hu) + N2.y * hv, (N0.z * bw + N1.z * hu) + N2.z * hv);
+                    float n2 = dot(Ns, Ns);
+                    Ns = n2 > 0.0f ? Ns * (1.0f / sqrtf(n2)) : Ng;
+                    if (dot(Ng, d) > 0.0f) Ng = neg(Ng);
+                    if (dot(Ns, Ng) < 0.0f) Ns = neg(Ns);
+                    float tu = (P0.w * bw + P1.w * hu) + P2.w * hv;
+                    float tvv = (N0.w * bw + N1.w * hu) + N2.w * hv;
+                    uint32_t mi = sc.tri_material[prim];
+                    if (mi >= sc.n_materials) mi = 0;
+                    const float4 *M4 = reinterpret_cast<const float4 *>(sc.materials + mi);
+                    const float4 mc = M4[0], mp = M4[1];
+                    f3 base = mk3(mc.x, mc.y, mc.z);
+                    float rough = mp.x, metal = mp.y;
+                    const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
+                    if (atex < sc.n_images) {
+                        const float4 tex = texture_lookup(sc, atex, tu, tvv, true);
+                        base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
+                    }
+                    if (mtex < sc.n_images) {
+                        const float4 tex = texture_lookup(sc, mtex, tu, tvv, false);
+                        rough *= tex.y; metal *= tex.z;
+                    }
+                    const Surface sf = make_surface(base, rough, metal);
+                    const f3 V = neg(d);
+                    const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
+                    const float pspec = spec_probability(sf, NoV);
+                    uint32_t x = 0, y = 0;
+                    slot_to_pixel(p, slot, x, y);
+                    const uint32_t pixel = y * p.width + x;
+                    Rng rg = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_SHADE);
+                    float r0 = rng_next(rg), r1 = rng_next(rg), r2 = rng_next(rg);
+                    float r3 = rng_next(rg), r4 = rng_next(rg), r5 = rng_next(rg);
+                    noise_shift(nz, x, y, seed_counter, r4, r5);
+                    float am = max2(max2(fabsf(P.x), fabsf(P.y)), fabsf(P.z));
+                    float eps = 1.0e-4f * (1.0f + am);
+                    const f3 Po = mk3(P.x + Ng.x * eps, P.y + Ng.y * eps, P.z + Ng.z * eps);
+                    // next-event estimation
+                    if (sc.n_lights) {
+                        uint32_t li = (uint32_t)(r0 * (float)sc.n_lights);
+                        if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
+                        const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + li);
+                        const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
+                        const float Le = lo4.w, hw = t4.w, hh = b4.w;
+                        float a = (2.0f * r1 - 1.0f) * hw, bq = (2.0f * r2 - 1.0f) * hh;
+                        f3 qp = mk3((lo4.x + t4.x * a) + b4.x * bq, (lo4.y + t4.y * a) + b4.y * bq, (lo4.z + t4.z * a) + b4.z * bq);
+                        f3 w = qp - Po;
+                        float d2 = dot(w, w);
+                        if (Le > 0.0f && d2 > 0.0f) {
+                            float dist = sqrtf(d2);
+                            f3 wi = w * (1.0f / dist);
+                            float cl = -dot(mk3(n4.x, n4.y, n4.z), wi);
+                            if (cl > 0.0f) {
+                                f3 f;
+                                float pb;
+                                bsdf_eval(sf, Ns, Ng, V, NoV, pspec, wi, f, pb);
+                                if (pb > 0.0f) {
+                                    float area = 4.0f * (hw * hh);
+                                    float pl = (d2 / (cl * area)) * inv_nl;
+                                    float pl2 = pl * pl;
+                                    float wm = pl2 / (pl2 + pb * pb);
+                                    float NoL = dot(Ns, wi);
+                                    float k = ((NoL * Le) * wm) / pl;
+                                    f3 contrib = mk3((T.x * f.x) * k, (T.y * f.y) * k, (T.z * f.z) * k);
+                                    if (contrib.x > 0.0f || contrib.y > 0.0f || contrib.z > 0.0f) {
+                                        want_shadow = true;
+                                        so4 = make_float4(Po.x, Po.y, Po.z, dist * 0.999f);
+                                        sd4 = make_float4(wi.x, wi.y, wi.z, o4.w);
+                                        sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // BSDF sample -> next ray
+                    if (!last_bounce) {
+                        f3 Ln, wgt;
+                        float pdf;
+                        if (bsdf_sample(sf, Ns, Ng, V, NoV, pspec, r3, r4, r5, Ln, wgt, pdf)) {
+                            f3 Tn = mk3(T.x * wgt.x, T.y * wgt.y, T.z * wgt.z);
+                            if (Tn.x > 0.0f || Tn.y > 0.0f || Tn.z > 0.0f) {
+                                want_next = true;
+                                no4 = make_float4(Po.x, Po.y, Po.z, o4.w);
+                                nd4 = make_float4(Ln.x, Ln.y, Ln.z, pdf);
+                                nT4 = make_float4(Tn.x, Tn.y, Tn.z, 0.f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const uint32_t si = wave_compact(want_shadow, &ctr->shcount[bounce]);
+        if (want_shadow) { sq.o[si] = so4; sq.d[si] = sd4; sq.c[si] = sc4; }
+        const uint32_t ni = wave_compact(want_next, &ctr->qcount[bounce + 1]);
+        if (want_next) { qout.o[ni] = no4; qout.d[ni] = nd4; qout.T[ni] = nT4; }
+        const unsigned long long smask = __ballot(is_surface);
+        if ((threadIdx.x & 63u) == 0 && smask) atomicAdd(&ctr->shaded[bounce], (uint32_t)__popcll(smask));
+    }
+}
+
+// ------------------------------------------------------------------ accumulation (SPEC §13)
+__global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const float4 *Lsum, float4 *accum) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(p, slot, x, y)) continue;
+        const float4 L = Lsum[slot];
+        const size_t px = (size_t)y * p.width + x;
+        if (p.frame_count == 1u) accum[px] = make_float4(L.x, L.y, L.z, 1.0f);
+        else {
+            float4 a = accum[px];
+            a.x = a.x + L.x; a.y = a.y + L.y; a.z = a.z + L.z; a.w = a.w + 1.0f;
+            accum[px] = a;
+        }
+    }
+}
+
+__global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long c = 0, s = 0, sh = 0;
+    for (uint32_t b = 0; b < bounces; ++b) { c += ctr->qcount[b]; s += ctr->shcount[b]; sh += ctr->shaded[b]; }
+    tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
+}
+
+// mean radiance (a = 1 where sampled) and sRGB8 (SPEC §13.2)
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4 *accum, float4 *mean, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = accum[i];
+    mean[i] = a.w > 0.0f ? make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ uint8_t encode_srgb8(float c) {
+    c = clampf(c, 0.0f, 1.0f);
+    float s = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 0.41666666f) - 0.055f;
+    return (uint8_t)(s * 255.0f + 0.5f);
+}
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float4 *accum, uchar4 *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = accum[i];
+    const bool ok = a.w > 0.0f;
+    out[i] = make_uchar4(encode_srgb8(ok ? a.x / a.w : 0.f), encode_srgb8(ok ? a.y / a.w : 0.f), encode_srgb8(ok ? a.z / a.w : 0.f), 255);
+}
+
+// stand-alone ray queries (lpt_trace_closest / lpt_trace_occluded)
+__global__ __launch_bounds__(kBlock) void k_query_occluded(DScene sc, const float4 *o, const float4 *d, uint8_t *out, uint32_t n) {
+    __shared__ int lds_stack[kStackSize * kBlock];
+    int *stack = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 o4 = o[i], d4 = d[i];
+    Hit h;
+    uint32_t a = 0, b = 0;
+    out[i] = traverse<true, false>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, a, b) ? 1 : 0;
+}
+
+}  // namespace lptd

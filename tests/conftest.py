@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cornell_glb():
+    with open(os.path.join(ROOT, "tests", "golden", "cornell-box.glb"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def device():
+    import loupiote_amd as lp
+    dev = lp.Device(0)
+    yield dev
+    dev.close()
