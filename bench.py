@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the path-tracing hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza"):
+  synthetic_atrium(seed=2) — the Sponza STAND-IN (the real asset is absent) —
+  1920x1080, 4 spp (= 4 raytrace() calls with accumulate), path depth 8, camera = the reference's
+  start pose.  One "step" = one such frame: reset_accumulation(); accumulate=true;
+  4 x Renderer::raytrace(view); for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
+  Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
+  N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
+  N grows ("strong" scaling of one frame).
+
+value = (closest-hit + shadow rays traced by all ranks in the K timed steps) / wall time, in
+Mrays/s, with barrier + torch.cuda.synchronize() on both sides and the MAX over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import loupiote_amd as lp  # noqa: E402
+from loupiote_amd import scenes, testing as T  # noqa: E402
+
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 4, 8
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class _DevBuf:
+    """exposes a raw device pointer to torch (plumbing for torch.distributed only)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(desc, view, threads):
+    """The CPU oracle ("port") timed on the host cores on a bounded sample of the same workload:
+    whole 1920x1080 frames of 1 spp each (the same seeds the GPU step uses for its 1st, 2nd ... sample),
+    as many of the 4 as fit in ~15 s of wall time."""
+    from oracle import orc  # checker only: the baseline leg, never the product path
+    s = scenes.to_oracle(desc)
+    sc = orc.OracleScene.from_scene(s, probe=desc["probe"])
+    rays, secs, frames = 0, 0.0, 0
+    while frames < SPP and secs < 15.0:
+        t0 = time.perf_counter()
+        _, cnt = sc.render(WIDTH, HEIGHT, view, T.VFOV, DEPTH, frames=1, seed_counter=frames * DEPTH, threads=threads, want_counters=True)
+        secs += time.perf_counter() - t0
+        rays += cnt.closest + cnt.shadow
+        frames += 1
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "oracle/lpt_oracle.c (scalar C, pthreads, 16x16 tiles), %d of the %d spp of the same 1920x1080 depth-8 frame "
+                      "(%.1f Mrays in %.1f s)" % (frames, SPP, rays / 1e6, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default="atrium")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    dev = lp.Device(local_rank)
+    desc = scenes.synthetic_atrium()
+    scene = scenes.to_product(desc)
+    sg = lp.SceneGPU.new_from_scene(scene, dev)
+    probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+    r = lp.Renderer(dev, (WIDTH, HEIGHT))
+    r.downsample_factor = 1.0
+    r.resize(dev, sg, probe, (WIDTH, HEIGHT))
+    r.set_max_bounces(DEPTH)
+    r.set_vfov(T.VFOV)
+    if world > 1:
+        r.set_shard(rank, world, 32, 8)
+        r.set_resources(dev, sg, probe)
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+
+    ext = torch.cuda.ExternalStream(dev.stream(), device=torch.device("cuda", local_rank))
+    ptr, nbytes = r.radiance_device_ptr()
+    accum = torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank))
+    frame = torch.empty_like(accum) if world > 1 else None
+
+    def step():
+        r.reset_accumulation()
+        r.accumulate = True
+        for _ in range(SPP):
+            r.raytrace(view)
+        if world > 1:
+            # radiance reduce over xGMI: ordered after the renderer's stream, which the next
+            # frame's kernels in turn wait on (torch issues the RCCL op relative to `ext`)
+            with torch.cuda.stream(ext):
+                frame.copy_(accum, non_blocking=True)
+                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.reset_ray_counts()
+    r.enable_timings(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timings = r.timings()
+    r.enable_timings(False)
+    counts = r.ray_counts()
+
+    tl = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([counts.closest, counts.shadow, counts.shaded], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(tl.item())
+    closest, shadow, shaded = [float(x) for x in rays.tolist()]
+
+    # ---- roofline of the dominant kernel (k_intersect), rank 0: algorithmic bytes per launch
+    # = rays/launch * (32 B ray read + 16 B hit write + N*64 B nodes + T*48 B triangles), with N, T
+    # (mean nodes visited / triangles tested per closest-hit ray) measured by the stats variant of
+    # the same kernel on the same frames, outside the timed region.
+    r.enable_stats(True)
+    r.reset_ray_counts()
+    step()
+    fence()
+    st = r.ray_counts()
+    r.enable_stats(False)
+    n_bar = st.nodes / max(st.closest, 1)
+    t_bar = st.tris / max(st.closest, 1)
+    ns_bar = st.shadow_nodes / max(st.shadow, 1)
+    ts_bar = st.shadow_tris / max(st.shadow, 1)
+    b_ray = 32.0 + 16.0 + n_bar * 64.0 + t_bar * 48.0
+    i_ms, i_launches = timings["intersection"]
+    rays_per_launch = counts.closest / max(i_launches, 1)
+    avg_ms = i_ms / max(i_launches, 1)
+    achieved = (rays_per_launch * b_ray) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_intersect_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza; 1/2/4/8 GPU",
+            "value": (closest + shadow) / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in, 262144 tris], 1920x1080, 4 spp, depth 8, "
+                                   "camera (-10,1,0)->(1,0.35,0); step = 1 frame (4 x raytrace + reduce)",
+                       "tiles": "32x8 interleaved, tile_id mod N", "rays_per_step": (closest + shadow) / args.steps,
+                       "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
+            "ms_per_frame": elapsed / args.steps * 1e3,
+            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": i_launches, "rays_per_launch": rays_per_launch,
+                         "bytes_per_ray": b_ray, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
+                         "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar},
+            "stage_ms_per_step": {k: v[0] / args.steps for k, v in timings.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(desc, view, os.cpu_count() or 1)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+    probe.close()
+    sg.close()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

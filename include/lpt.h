@@ -126,13 +126,15 @@ typedef struct lpt_ray_counts {
     uint64_t closest; /* closest-hit rays traced since the last reset */
     uint64_t shadow;  /* shadow (any-hit) rays traced                 */
     uint64_t shaded;  /* surface hits shaded                          */
-    uint64_t nodes;   /* BVH nodes visited (only when stats enabled)  */
-    uint64_t tris;    /* triangles tested  (only when stats enabled)  */
+    uint64_t nodes;   /* closest-hit kernel: BVH nodes visited (stats enabled only) */
+    uint64_t tris;    /* closest-hit kernel: triangles tested  (stats enabled only) */
+    uint64_t shadow_nodes; /* shadow kernel: nodes visited (stats enabled only)     */
+    uint64_t shadow_tris;  /* shadow kernel: triangles tested (stats enabled only)  */
 } lpt_ray_counts;
 
 typedef struct lpt_timing {
     char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation" */
-    float ms;       /* summed over the last raytrace() call */
+    float ms;       /* summed over every raytrace() since enable_timings(1) */
     uint32_t launches;
 } lpt_timing;
 

@@ -42,7 +42,7 @@ class AccelStats(C.Structure):
 
 
 class RayCounts(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris")]
+    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris", "shadow_nodes", "shadow_tris")]
 
 
 class Timing(C.Structure):

@@ -64,6 +64,7 @@ struct lpt_renderer {
     bool use_noise = false, stats = false, timings = false;
     // device memory
     uint32_t n_slots = 0;
+    uint32_t *n_slots_host = nullptr;  // pinned copy of n_slots (source of the async qcount[0] preset)
     Queue q[2]{};
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr, *accum = nullptr, *scratch = nullptr;
@@ -72,12 +73,16 @@ struct lpt_renderer {
     void *default_probe = nullptr;
     void *noise = nullptr;
     uint32_t noise_w = 0, noise_h = 0;
-    // per-stage timing of the last raytrace()
-    static constexpr int kMaxEvents = 4 * kMaxBounces + 8;
-    hipEvent_t ev_start[kMaxEvents]{}, ev_stop[kMaxEvents]{};
-    int ev_stage[kMaxEvents]{};
-    int n_events = 0;
-    bool events_created = false;
+    // per-stage timing: a ring of event sets (one per raytrace() call) harvested lazily, so
+    // timing a run never stalls the host on the frame it has just enqueued
+    static constexpr int kRing = 8;
+    static constexpr int kMaxEvents = 3 * kMaxBounces + 4;
+    hipEvent_t *ev_start = nullptr, *ev_stop = nullptr;  // kRing * kMaxEvents each
+    int ev_stage[kRing][kMaxEvents]{};
+    int ev_count[kRing]{};
+    uint64_t ring_pos = 0;
+    double stage_ms[8]{};
+    uint32_t stage_launches[8]{};
 };
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
@@ -272,7 +277,7 @@ int lpt_trace_closest(lpt_device *dev, const lpt_scene_gpu *sg, const float *ori
     if (e == hipSuccess) e = hipMemcpyAsync(&ctr->qcount[0], &n, sizeof n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) {
         Queue q{dO, dD, nullptr};
-        const uint32_t blocks = std::min<uint32_t>(div_up(n, kBlock), (uint32_t)dev->compute_units * 4u);
+        const uint32_t blocks = div_up(n, kBlock);
         hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), 0, dev->stream, sg->d, q, dH, ctr, 0);
         e = hipGetLastError();
     }
@@ -351,6 +356,7 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
     HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->dev->stream));
     r->n_slots = n_slots;
+    *r->n_slots_host = n_slots;
     return LPT_OK;
 }
 
@@ -366,6 +372,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     hipError_t e = hipMalloc(&r->ctr, sizeof(FrameCounters));
     if (e == hipSuccess) e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
     if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
     if (e != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e)); }
@@ -383,9 +390,13 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     if (r->ctr) hipFree(r->ctr);
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
+    if (r->n_slots_host) hipHostFree(r->n_slots_host);
     if (r->noise) hipFree(r->noise);
-    if (r->events_created)
-        for (int i = 0; i < lpt_renderer::kMaxEvents; ++i) { hipEventDestroy(r->ev_start[i]); hipEventDestroy(r->ev_stop[i]); }
+    if (r->ev_start) {
+        for (int i = 0; i < lpt_renderer::kRing * lpt_renderer::kMaxEvents; ++i) { hipEventDestroy(r->ev_start[i]); hipEventDestroy(r->ev_stop[i]); }
+        delete[] r->ev_start;
+        delete[] r->ev_stop;
+    }
     delete r;
     return LPT_OK;
 }
@@ -498,24 +509,49 @@ int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
 int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_timings: null");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    if (flag && !r->events_created) {
-        for (int i = 0; i < lpt_renderer::kMaxEvents; ++i) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
-        r->events_created = true;
+    const int total = lpt_renderer::kRing * lpt_renderer::kMaxEvents;
+    if (flag && !r->ev_start) {
+        r->ev_start = new hipEvent_t[total];
+        r->ev_stop = new hipEvent_t[total];
+        for (int i = 0; i < total; ++i) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
+    }
+    if (flag) {  // (re)start accumulating
+        HIP_TRY(hipStreamSynchronize(r->dev->stream));
+        for (int k = 0; k < lpt_renderer::kRing; ++k) r->ev_count[k] = 0;
+        for (int i = 0; i < 8; ++i) { r->stage_ms[i] = 0.0; r->stage_launches[i] = 0; }
     }
     r->timings = flag != 0;
-    r->n_events = 0;
     return LPT_OK;
 }
 
+// fold one ring slot's finished events into the per-stage totals (waits for them if needed)
+static void harvest_slot(lpt_renderer *r, int slot) {
+    const int n = r->ev_count[slot];
+    for (int i = 0; i < n; ++i) {
+        const int e = slot * lpt_renderer::kMaxEvents + i;
+        float ms = 0.f;
+        hipEventSynchronize(r->ev_stop[e]);
+        if (hipEventElapsedTime(&ms, r->ev_start[e], r->ev_stop[e]) == hipSuccess) {
+            r->stage_ms[r->ev_stage[slot][i]] += ms;
+            r->stage_launches[r->ev_stage[slot][i]]++;
+        }
+    }
+    r->ev_count[slot] = 0;
+}
+static inline int cur_slot(const lpt_renderer *r) { return (int)(r->ring_pos % lpt_renderer::kRing); }
 static inline void stage_begin(lpt_renderer *r, int stage) {
-    if (!r->timings || r->n_events >= lpt_renderer::kMaxEvents) return;
-    r->ev_stage[r->n_events] = stage;
-    hipEventRecord(r->ev_start[r->n_events], r->dev->stream);
+    if (!r->timings) return;
+    const int slot = cur_slot(r);
+    if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
+    r->ev_stage[slot][r->ev_count[slot]] = stage;
+    hipEventRecord(r->ev_start[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->dev->stream);
 }
 static inline void stage_end(lpt_renderer *r) {
-    if (!r->timings || r->n_events >= lpt_renderer::kMaxEvents) return;
-    hipEventRecord(r->ev_stop[r->n_events], r->dev->stream);
-    r->n_events++;
+    if (!r->timings) return;
+    const int slot = cur_slot(r);
+    if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
+    hipEventRecord(r->ev_stop[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->dev->stream);
+    r->ev_count[slot]++;
 }
 
 int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
@@ -546,17 +582,23 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
     DProbe probe = r->probe ? r->probe->d : DProbe{(const uint8_t *)r->default_probe, 1u, 1u};
     DNoise nz{(const uint8_t *)r->noise, r->noise_w, r->noise_h, (r->use_noise && r->noise) ? 1u : 0u};
     const DScene &sc = r->sg->d;
-    r->n_events = 0;
+    if (r->timings) { r->ring_pos++; harvest_slot(r, cur_slot(r)); }
 
     if (p.n_slots) {
         HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 8u);
-        const uint32_t trace_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 4u);
+        const uint32_t trace_blocks = div_up(p.n_slots, kBlock);  // covers the queue capacity; idle blocks exit
 
         // "ray generation" (:444-448)
         stage_begin(r, ST_RAYGEN);
-        hipLaunchKernelGGL(k_raygen, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+        const bool dense = (r->w % r->tile_w == 0u) && (r->h % r->tile_h == 0u);
+        if (dense) {
+            HIP_TRY(hipMemcpyAsync(&r->ctr->qcount[0], r->n_slots_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_raygen<true>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+        } else {
+            hipLaunchKernelGGL(k_raygen<false>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+        }
         stage_end(r);
 
         uint32_t seed = r->seed;
@@ -639,6 +681,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     HIP_TRY(hipMemcpyAsync(&t, r->totals, sizeof t, hipMemcpyDeviceToHost, r->dev->stream));
     HIP_TRY(hipStreamSynchronize(r->dev->stream));
     out->closest = t.closest; out->shadow = t.shadow; out->shaded = t.shaded; out->nodes = t.nodes; out->tris = t.tris;
+    out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
     return LPT_OK;
 }
 
@@ -654,10 +697,12 @@ int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count)
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->dev->stream));
     lpt_timing acc[ST_COUNT];
-    for (int i = 0; i < ST_COUNT; ++i) { memset(&acc[i], 0, sizeof acc[i]); snprintf(acc[i].label, sizeof acc[i].label, "%s", kStageLabel[i]); }
-    for (int i = 0; i < r->n_events; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r->ev_start[i], r->ev_stop[i]) == hipSuccess) { acc[r->ev_stage[i]].ms += ms; acc[r->ev_stage[i]].launches++; }
+    if (r->ev_start) for (int k = 0; k < lpt_renderer::kRing; ++k) harvest_slot(r, k);
+    for (int i = 0; i < ST_COUNT; ++i) {
+        memset(&acc[i], 0, sizeof acc[i]);
+        snprintf(acc[i].label, sizeof acc[i].label, "%s", kStageLabel[i]);
+        acc[i].ms = (float)r->stage_ms[i];
+        acc[i].launches = r->stage_launches[i];
     }
     const int n = std::min(*inout_count, (int)ST_COUNT);
     if (out) for (int i = 0; i < n; ++i) out[i] = acc[i];

@@ -19,6 +19,7 @@ namespace lptd {
 constexpr int kMaxBounces = 64;
 constexpr int kStackSize = 32;  // >= bvh.cpp kMaxDepth + 2
 constexpr int kBlock = 256;
+constexpr uint32_t kChunk = 512;  // rays a wave dequeues per atomic (8 packets of 64)
 
 struct DNode2 {  // 64 B, mirrors lpt::Node2
     float4 a;    // lo0.xyz, hi0.x
@@ -55,9 +56,9 @@ struct FrameCounters {
     uint32_t ihead[kMaxBounces];
     uint32_t shead[kMaxBounces];
     uint32_t shaded[kMaxBounces];
-    unsigned long long nodes, tris;
+    unsigned long long nodes, tris, shadow_nodes, shadow_tris;
 };
-struct Totals { unsigned long long closest, shadow, shaded, nodes, tris; };
+struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris; };
 
 struct FrameParams {
     f3 origin, right, up, fwd;
@@ -92,6 +93,28 @@ __device__ __forceinline__ uint32_t wave_compact(bool valid, uint32_t *counter) 
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// block-aggregated stream compaction: ONE global atomic per 256-thread block and counter.
+// A single device-scope word sustains only ~88 returning atomics/us on MI355X, so a
+// per-wave atomic (32K of them for a 1080p queue) would cost more than the shading itself.
+// Must be called by every thread of the block (two barriers).  `lds` needs 8 uint32.
+__device__ __forceinline__ uint32_t block_compact(bool valid, uint32_t *counter, uint32_t *lds) {
+    const unsigned long long mask = __ballot(valid);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n = (uint32_t)__popcll(mask);
+    if (lane == 0) lds[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n0 = lds[0], n1 = lds[1], n2 = lds[2], n3 = lds[3];
+        const uint32_t total = n0 + n1 + n2 + n3;
+        const uint32_t base = total ? atomicAdd(counter, total) : 0u;
+        lds[4] = base; lds[5] = base + n0; lds[6] = base + n0 + n1; lds[7] = base + n0 + n1 + n2;
+    }
+    __syncthreads();
+    const uint32_t idx = lds[4 + wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // lds is reused by the next call
+    return idx;
+}
+
 __device__ __forceinline__ void noise_shift(const DNoise &nz, uint32_t x, uint32_t y, uint32_t seed_counter, float &r0, float &r1) {
     if (!nz.enabled) return;
     const uint8_t *t = nz.rgba + 4u * ((size_t)(y % nz.h) * nz.w + (x % nz.w));
@@ -107,9 +130,13 @@ __device__ __forceinline__ void noise_shift(const DNoise &nz, uint32_t x, uint32
 }
 
 // ------------------------------------------------------------------ ray generation
+// DENSE: every slot maps to a pixel (image is a whole number of tiles) -> queue index = slot and
+// the host presets qcount[0]; otherwise invalid slots are compacted away.
+template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Queue q, float4 *Lsum, FrameCounters *ctr) {
+    __shared__ uint32_t lds[8];
     const uint32_t stride = gridDim.x * blockDim.x;
-    // n_slots is a multiple of 64 (tile_w*tile_h is), so whole waves stay converged for the ballot
+    // n_slots is a multiple of 256 (tile area is), so whole blocks stay converged for the barriers
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
         uint32_t x = 0, y = 0;
         const bool valid = slot_to_pixel(p, slot, x, y);
@@ -128,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
                          (p.right.z * cx + p.up.z * cy) + p.fwd.z);
             d = normalize(dir);
         }
-        const uint32_t idx = wave_compact(valid, &ctr->qcount[0]);
+        const uint32_t idx = DENSE ? slot : block_compact(valid, &ctr->qcount[0], lds);
         if (valid) {
             q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(slot));
             q.d[idx] = make_float4(d.x, d.y, d.z, -1.0f);
@@ -251,22 +278,17 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, Queue q, float4
     __shared__ int lds_stack[kStackSize * kBlock];
     int *stack = lds_stack + threadIdx.x;
     const uint32_t count = ctr->qcount[bounce];
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->ihead[bounce], 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        const uint32_t i = base + lane;
-        if (i < count) {
-            const float4 o4 = q.o[i], d4 = q.d[i];
-            const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-            Hit h;
-            traverse<false, STATS>(sc, o, d, LPT_T_INF, stack, h, n_nodes, n_tris);
-            intersect_lights(sc, o, d, h);
-            hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-        }
+    // static packets: block b owns rays [256 b, 256 b + 256); the grid covers the queue's
+    // capacity and blocks beyond the live count exit at once (no dequeue atomics: one
+    // device-scope word sustains only ~88 atomics/us, the hardware dispatcher is free)
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        const float4 o4 = q.o[i], d4 = q.d[i];
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        Hit h;
+        traverse<false, STATS>(sc, o, d, LPT_T_INF, stack, h, n_nodes, n_tris);
+        intersect_lights(sc, o, d, h);
+        hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
     }
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
@@ -279,30 +301,22 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DScene sc, ShadowQueue sq, fl
     __shared__ int lds_stack[kStackSize * kBlock];
     int *stack = lds_stack + threadIdx.x;
     const uint32_t count = ctr->shcount[bounce];
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->shead[bounce], 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        const uint32_t i = base + lane;
-        if (i < count) {
-            const float4 o4 = sq.o[i], d4 = sq.d[i];
-            Hit h;
-            const bool occluded = traverse<true, STATS>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, n_nodes, n_tris);
-            if (!occluded) {
-                const uint32_t slot = __float_as_uint(d4.w);
-                const float4 c = sq.c[i];
-                float4 L = Lsum[slot];
-                L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
-                Lsum[slot] = L;
-            }
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+        const float4 o4 = sq.o[i], d4 = sq.d[i];
+        Hit h;
+        const bool occluded = traverse<true, STATS>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, n_nodes, n_tris);
+        if (!occluded) {
+            const uint32_t slot = __float_as_uint(d4.w);
+            const float4 c = sq.c[i];
+            float4 L = Lsum[slot];
+            L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+            Lsum[slot] = L;
         }
     }
     if (STATS) {
-        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
-        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        atomicAdd(&ctr->shadow_nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->shadow_tris, (unsigned long long)n_tris);
     }
 }
 
@@ -372,9 +386,11 @@ __device__ __forceinline__ f3 env_lookup(const DProbe &pr, f3 d) {
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
                                                   uint32_t seed_counter) {
+    __shared__ uint32_t lds[8];
     const uint32_t count = ctr->qcount[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounded = (count + 63u) & ~63u;  // keep whole waves in the loop for the ballots
+    const uint32_t rounded = (count + 255u) & ~255u;  // keep whole blocks in the loop for the barriers
+    uint32_t n_surface = 0;
     const bool last_bounce = (uint32_t)bounce + 1u >= p.max_bounces;
     const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
@@ -510,13 +526,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                 }
             }
         }
-        const uint32_t si = wave_compact(want_shadow, &ctr->shcount[bounce]);
+        const uint32_t si = block_compact(want_shadow, &ctr->shcount[bounce], lds);
         if (want_shadow) { sq.o[si] = so4; sq.d[si] = sd4; sq.c[si] = sc4; }
-        const uint32_t ni = wave_compact(want_next, &ctr->qcount[bounce + 1]);
-        if (want_next) { qout.o[ni] = no4; qout.d[ni] = nd4; qout.T[ni] = nT4; }
-        const unsigned long long smask = __ballot(is_surface);
-        if ((threadIdx.x & 63u) == 0 && smask) atomicAdd(&ctr->shaded[bounce], (uint32_t)__popcll(smask));
+        if (!last_bounce) {
+            const uint32_t ni = block_compact(want_next, &ctr->qcount[bounce + 1], lds);
+            if (want_next) { qout.o[ni] = no4; qout.d[ni] = nd4; qout.T[ni] = nT4; }
+        }
+        n_surface += is_surface ? 1u : 0u;
     }
+    // surface-hit count: wave reduce, one atomic per wave per LAUNCH
+    for (int off = 32; off > 0; off >>= 1) n_surface += __shfl_down(n_surface, off);
+    if ((threadIdx.x & 63u) == 0 && n_surface) atomicAdd(&ctr->shaded[bounce], n_surface);
 }
 
 // ------------------------------------------------------------------ accumulation (SPEC §13)
@@ -541,6 +561,7 @@ __global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces
     unsigned long long c = 0, s = 0, sh = 0;
     for (uint32_t b = 0; b < bounces; ++b) { c += ctr->qcount[b]; s += ctr->shcount[b]; sh += ctr->shaded[b]; }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
+    tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
 }
 
 // mean radiance (a = 1 where sampled) and sRGB8 (SPEC §13.2)

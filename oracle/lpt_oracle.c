@@ -769,10 +769,16 @@ static void *worker(void *arg) {
     job_t *j = (job_t *)arg;
     const orc_render_params *p = j->p;
     orc_counters local; memset(&local, 0, sizeof local);
+    /* work items: 16x16 pixel tiles of the crop window, handed out by an atomic counter */
+    const uint32_t TW = 16u, TH = 16u;
+    const uint32_t ntx = (j->x1 - j->x0 + TW - 1u) / TW, nty = (j->y1 - j->y0 + TH - 1u) / TH;
     for (;;) {
-        uint32_t y = j->y0 + atomic_fetch_add(&j->next_row, 1u);
-        if (y >= j->y1) break;
-        for (uint32_t x = j->x0; x < j->x1; ++x) {
+        uint32_t tile = atomic_fetch_add(&j->next_row, 1u);
+        if (tile >= ntx * nty) break;
+        const uint32_t ty0 = j->y0 + (tile / ntx) * TH, tx0 = j->x0 + (tile % ntx) * TW;
+        const uint32_t ty1 = ty0 + TH < j->y1 ? ty0 + TH : j->y1, tx1 = tx0 + TW < j->x1 ? tx0 + TW : j->x1;
+        for (uint32_t y = ty0; y < ty1; ++y)
+        for (uint32_t x = tx0; x < tx1; ++x) {
             if (!owns_pixel(p, x, y)) continue;
             float *acc = j->accum + 4 * ((size_t)y * p->width + x);
             uint32_t seed = p->seed_counter;
