@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): kernel-trace stats + separate PMC passes for the bench workload.
+# usage: tools/profile.sh <tag>     -> gpurun_out/prof_<tag>/{trace,pmc1,pmc2,pmc3}
+# PMC passes are collected on their own (never combined with --sys-trace etc.); the program after
+# `--` is python3 itself (no env/bash hop).
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o p -- python3 $ARGS > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc2 -o p -- python3 $ARGS > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc3 -o p -- python3 $ARGS > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc4 -o p -- python3 $ARGS > $OUT/pmc4.log 2>&1
+find $OUT -name "*.csv" | xargs ls -la
+for f in $OUT/*.log; do echo "== $f"; grep -E '"value"|rror' $f | cut -c1-200 | head -3; done
