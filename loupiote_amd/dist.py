@@ -1,0 +1,44 @@
+"""One-process-per-GPU plumbing: pixel-tile ownership and the radiance reduce.
+
+The reference is single-GPU; this is new functionality required by the north
+star: frames shard by pixel tile across the GPUs of a node and the accumulated radiance buffer
+is summed to rank 0 with one collective per frame (RCCL over xGMI when the tensors live on
+GPUs, gloo in the CPU tests).  No arithmetic on radiance happens here except that sum.
+"""
+import numpy as np
+
+TILE_W, TILE_H = 32, 8
+
+
+def tile_grid(width, height, tile_w=TILE_W, tile_h=TILE_H):
+    return (width + tile_w - 1) // tile_w, (height + tile_h - 1) // tile_h
+
+
+def owner_map(width, height, world_size, tile_w=TILE_W, tile_h=TILE_H):
+    """rank that owns each pixel: tile id (row-major over the tile grid) mod world_size —
+    the rule lpt_renderer_set_shard implements on the device (kernels.h slot_to_pixel)."""
+    tiles_x, _ = tile_grid(width, height, tile_w, tile_h)
+    y, x = np.mgrid[0:height, 0:width]
+    tile = (y // tile_h) * tiles_x + (x // tile_w)
+    return (tile % world_size).astype(np.int32)
+
+
+def owned_mask(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
+    return owner_map(width, height, world_size, tile_w, tile_h) == rank
+
+
+def owned_slots(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
+    """number of pixel slots a rank allocates (whole tiles, including out-of-image padding)"""
+    tiles_x, tiles_y = tile_grid(width, height, tile_w, tile_h)
+    n_tiles = tiles_x * tiles_y
+    owned = (n_tiles - rank + world_size - 1) // world_size if n_tiles > rank else 0
+    return owned * tile_w * tile_h
+
+
+def reduce_radiance(buf, dst=0):
+    """sum the (rgb-sum, sample-count) accumulation buffers of all ranks onto `dst`.
+    Ownership is disjoint, so the sum is a gather; a reduce is the contract (north star)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)
+    return buf

@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py — tile ownership (loupiote_amd.dist), one
+radiance reduce per frame to rank 0, MAX-over-ranks timing reduction — with the oracle standing in
+for the GPU renderer on each rank (there is no GPU here; the device-side ownership rule is checked
+against the same owner_map in the -m gpu tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from loupiote_amd import dist as D, testing as T
+    glb = open(os.path.join(ROOT, "tests", "golden", "cornell-box.glb"), "rb").read()
+    W, H, bounces, frames = 96, 40, 3, 2
+    # each rank renders only its tiles (the oracle applies the same tile_id mod N rule)
+    from oracle import gltf_oracle as G, orc
+    s = G.Scene()
+    G.load_gltf(glb, s)
+    s.lights[0] = T.cornell_light()[0]
+    sc = orc.OracleScene.from_scene(s, probe=T.CORNELL_PROBE)
+    acc, cnt = sc.render(W, H, T.look(T.CORNELL_EYE, T.CORNELL_DIR), T.VFOV, bounces, frames=frames, rank=rank, world_size=world,
+                         tile_w=D.TILE_W, tile_h=D.TILE_H, threads=2, want_counters=True)
+    mask = D.owned_mask(W, H, rank, world)
+    assert np.array_equal(acc[..., 3] > 0, mask)
+    buf = torch.from_numpy(acc.copy())
+    D.reduce_radiance(buf, dst=0)                       # the one data-path collective
+    rays = torch.tensor([cnt.closest + cnt.shadow], dtype=torch.float64)
+    dist.all_reduce(rays, op=dist.ReduceOp.SUM)         # whole-job ray count
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)            # MAX over ranks, as bench.py does with elapsed time
+    assert float(t.item()) == 0.5 + (world - 1)
+    if rank == 0:
+        full, fc = sc.render(W, H, T.look(T.CORNELL_EYE, T.CORNELL_DIR), T.VFOV, bounces, frames=frames, threads=2, want_counters=True)
+        ok = buf.numpy().tobytes() == full.tobytes() and int(rays.item()) == fc.closest + fc.shadow
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_sharded_reduce_equals_single_rank(tmp_path):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_owner_map_properties():
+    sys.path.insert(0, ROOT)
+    from loupiote_amd import dist as D
+    for (w, h, n) in [(1920, 1080, 8), (200, 120, 3), (33, 9, 2), (31, 7, 4)]:
+        om = D.owner_map(w, h, n)
+        assert om.min() >= 0 and om.max() < n
+        total = 0
+        for r in range(n):
+            m = D.owned_mask(w, h, r, n)
+            total += int(m.sum())
+            assert D.owned_slots(w, h, r, n) >= int(m.sum())
+        assert total == w * h
+        # interleaved: neighbouring tiles go to different ranks when n > 1
+        if w > D.TILE_W and n > 1:
+            assert om[0, 0] != om[0, D.TILE_W]
+    # 1080p splits evenly over 8 GPUs (8100 tiles)
+    om = D.owner_map(1920, 1080, 8)
+    counts = np.bincount(om.reshape(-1), minlength=8)
+    assert counts.max() - counts.min() <= D.TILE_W * D.TILE_H

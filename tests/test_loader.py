@@ -1,0 +1,199 @@
+"""CPU: glTF loader of the product (lpt_load_gltf, C++) against the oracle's numpy restatement of
+reference crates/lib/src/loaders/gltf.rs:46-156 — byte-exact flat arrays — plus the error
+behaviour (Error::FileNotFound on every parse failure, gltf.rs:49-53) and append semantics."""
+import base64
+import io
+import json
+import struct
+
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from oracle import gltf_oracle as G
+
+ARRAYS = ["materials", "entries", "vertices", "indices", "instances", "lights"]
+
+
+def both(data, pre=None):
+    s, o = lp.Scene(), G.Scene()
+    if pre is not None:
+        lp.loaders.load_gltf(pre, s)
+        G.load_gltf(pre, o)
+    lp.loaders.load_gltf(data, s)
+    G.load_gltf(data, o)
+    return s, o
+
+
+def assert_same(s, o):
+    for name in ARRAYS:
+        a, b = getattr(s, name), getattr(o, name)
+        assert a.shape == b.shape, name
+        assert a.tobytes() == b.tobytes(), name
+    assert s.counts().images == len(o.images)
+    for i, img in enumerate(o.images):
+        assert np.array_equal(s.image(i), img)
+
+
+def make_gltf(meshes, nodes, materials=(), images=(), textures=(), glb=False):
+    """tiny glTF writer: meshes = [[prim dict(pos, nrm?, uv?, idx?, mode?, material?, idx_type?)]]"""
+    blob = bytearray()
+    views, accessors = [], []
+
+    def add(arr, ctype, atype, stride=None):
+        while len(blob) % 4:
+            blob.append(0)
+        raw = np.ascontiguousarray(arr).tobytes()
+        view = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(raw)}
+        if stride:
+            view["byteStride"] = stride
+        views.append(view)
+        blob.extend(raw)
+        accessors.append({"bufferView": len(views) - 1, "componentType": ctype, "count": int(np.asarray(arr).shape[0]), "type": atype})
+        return len(accessors) - 1
+
+    jm = []
+    for prims in meshes:
+        jp = []
+        for p in prims:
+            attrs = {}
+            if "pos" in p:
+                attrs["POSITION"] = add(np.asarray(p["pos"], "<f4"), 5126, "VEC3")
+            if "nrm" in p:
+                attrs["NORMAL"] = add(np.asarray(p["nrm"], "<f4"), 5126, "VEC3")
+            if "uv" in p:
+                attrs["TEXCOORD_0"] = add(np.asarray(p["uv"], "<f4"), 5126, "VEC2")
+            d = {"attributes": attrs}
+            if "idx" in p:
+                dt, ct = {"u8": ("u1", 5121), "u16": ("<u2", 5123), "u32": ("<u4", 5125)}[p.get("idx_type", "u16")]
+                d["indices"] = add(np.asarray(p["idx"], dt), ct, "SCALAR")
+            if "mode" in p:
+                d["mode"] = p["mode"]
+            if "material" in p:
+                d["material"] = p["material"]
+            jp.append(d)
+        jm.append({"primitives": jp})
+    jimages = []
+    for img in images:
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(img)})
+        blob.extend(img)
+        jimages.append({"bufferView": len(views) - 1, "mimeType": "image/png"})
+    js = {"asset": {"version": "2.0"}, "meshes": jm, "nodes": list(nodes), "accessors": accessors, "bufferViews": views,
+          "materials": list(materials), "images": jimages, "textures": [{"source": t} for t in textures]}
+    if glb:
+        js["buffers"] = [{"byteLength": len(blob)}]
+        j = json.dumps(js).encode()
+        j += b" " * (-len(j) % 4)
+        b = bytes(blob) + b"\0" * (-len(blob) % 4)
+        return struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(j) + 8 + len(b)) + struct.pack("<II", len(j), 0x4E4F534A) + j + struct.pack("<II", len(b), 0x004E4942) + b
+    js["buffers"] = [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()}]
+    return json.dumps(js).encode()
+
+
+def png_bytes(arr):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+QUAD = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+QN = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+QUV = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+
+
+def test_cornell_box_matches_oracle_loader(cornell_glb):
+    s, o = both(cornell_glb)
+    assert_same(s, o)
+    c = s.counts()
+    # 5 primitives -> 5 BLAS entries + 5 instances + 3 materials, after the dummies
+    assert (c.entries, c.instances, c.materials, c.images) == (6, 6, 4, 0)
+    assert c.indices == 34 * 3 and c.vertices == 103
+    m = s.materials
+    assert np.allclose(m["color"][2], (0, 1, 0, 1)) and m["albedo_texture"][1] == lp.INVALID_INDEX
+    assert np.isclose(m["roughness"][1], 0.4) and m["reflectivity"][1] == 0
+
+
+def test_append_semantics_offsets(cornell_glb):
+    """loading twice appends: bvh_offset / mat_offset are taken before the load (gltf.rs:60,109-110)"""
+    s, o = both(cornell_glb, pre=cornell_glb)
+    assert_same(s, o)
+    inst = s.instances
+    assert list(inst["blas_index"]) == [0] + list(range(1, 11))
+    assert list(inst["material_index"][6:]) == [4, 4, 4, 5, 6]
+
+
+@pytest.mark.parametrize("glb", [False, True])
+def test_synthetic_variants_match_oracle(glb):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)      # RGB: alpha stays 0 (gltf.rs:26-38)
+    img2 = rng.integers(0, 256, (4, 4, 4), dtype=np.uint8)
+    strip = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1], [0, 2, 1]], np.float32)
+    meshes = [
+        [{"pos": QUAD, "nrm": QN, "uv": QUV, "idx": [0, 1, 2, 0, 2, 3], "material": 0},
+         {"pos": QUAD + 2, "idx": [0, 1, 2, 0, 2, 3], "idx_type": "u32", "material": 1},           # no normals -> generated
+         {"nrm": QN},                                                                                # no POSITION -> skipped
+         {"pos": QUAD, "mode": 1},                                                                   # LINES -> skipped
+         {"pos": QUAD - 3, "nrm": QN}],                                                              # non-indexed (count 4 -> 1 tri), no material
+        [{"pos": strip, "mode": 5, "idx": [0, 1, 2, 3, 4], "idx_type": "u8"},
+         {"pos": strip, "mode": 6}],
+    ]
+    nodes = [{"mesh": 0, "translation": [1, 2, 3], "rotation": [0.1825742, 0.3651484, 0.5477226, 0.7302967], "scale": [1, 2, 0.5]},
+             {"mesh": 1, "matrix": [1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, 4, 5, 6, 1]},
+             {"name": "empty"},
+             {"mesh": 0}]
+    materials = [{"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1], "roughnessFactor": 0.3, "metallicFactor": 0.9,
+                                           "baseColorTexture": {"index": 1}, "metallicRoughnessTexture": {"index": 0}}},
+                 {}]
+    data = make_gltf(meshes, nodes, materials, images=[png_bytes(img), png_bytes(img2)], textures=[1, 0], glb=glb)
+    s, o = both(data)
+    assert_same(s, o)
+    c = s.counts()
+    assert c.entries == 1 + 5 and c.instances == 1 + 3 + 2 + 3
+    m = s.materials
+    assert m["albedo_texture"][1] == 0 and m["mra_texture"][1] == 1          # through textures[i].source
+    assert m["roughness"][2] == 1.0 and m["reflectivity"][2] == 1.0           # glTF defaults
+    inst = s.instances
+    assert list(inst["blas_index"][1:4]) == [1, 2, 3] and list(inst["material_index"][1:4]) == [1, 2, 0]
+    assert np.array_equal(s.image(0)[..., 3], np.zeros((5, 7), np.uint8))
+    # a failed load leaves the scene untouched
+    before = {n: getattr(s, n).tobytes() for n in ARRAYS}
+    with pytest.raises(lp.Error):
+        lp.loaders.load_gltf(data[: len(data) // 2], s)
+    assert before == {n: getattr(s, n).tobytes() for n in ARRAYS}
+
+
+@pytest.mark.parametrize("bad", [b"", b"garbage", b"glTF\x02\x00\x00\x00\x10\x00\x00\x00", b'{"asset":{}, "meshes": [{"primitives": [{"attributes": {"POSITION": 3}}]}]}'])
+def test_parse_failures_are_file_not_found(bad):
+    s = lp.Scene()
+    with pytest.raises(lp.Error) as e:
+        lp.loaders.load_gltf(bad, s)
+    assert e.value.kind == "FileNotFound" and str(e.value).startswith("file not found")
+    with pytest.raises(FileNotFoundError):
+        G.load_gltf(bad, G.Scene())
+
+
+def test_load_gltf_path(tmp_path, cornell_glb):
+    p = tmp_path / "c.glb"
+    p.write_bytes(cornell_glb)
+    s = lp.Scene()
+    lp.loaders.load_gltf_path(p, s)
+    assert s.counts().entries == 6
+    with pytest.raises(lp.Error) as e:
+        lp.loaders.load_gltf_path(tmp_path / "missing.glb", s)
+    assert e.value.kind == "FileNotFound"
+
+
+def test_png_decoder_matches_pil():
+    rng = np.random.default_rng(11)
+    for shape in [(33, 17, 4), (16, 16, 3), (9, 31)]:
+        arr = rng.integers(0, 256, shape, dtype=np.uint8)
+        data = make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[png_bytes(arr)], textures=[0])
+        s = lp.Scene()
+        lp.loaders.load_gltf(data, s)
+        got = s.image(0)
+        want = np.zeros(arr.shape[:2] + (4,), np.uint8)
+        want[..., : (arr.shape[2] if arr.ndim == 3 else 1)] = arr if arr.ndim == 3 else arr[..., None]
+        assert np.array_equal(got, want)
