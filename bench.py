@@ -152,7 +152,8 @@ def main():
     t_bar = st.tris / max(st.closest, 1)
     ns_bar = st.shadow_nodes / max(st.shadow, 1)
     ts_bar = st.shadow_tris / max(st.shadow, 1)
-    b_ray = 32.0 + 16.0 + n_bar * 64.0 + t_bar * 48.0
+    accel = sg.stats()
+    b_ray = 32.0 + 16.0 + n_bar * accel.node_bytes + t_bar * accel.tri_bytes
     i_ms, i_launches = timings["intersection"]
     rays_per_launch = counts.closest / max(i_launches, 1)
     avg_ms = i_ms / max(i_launches, 1)
@@ -190,6 +191,8 @@ def main():
                          "bytes_per_ray": b_ray, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar},
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in timings.items()},
+            "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
+                      "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, view, os.cpu_count() or 1)

@@ -6,10 +6,14 @@
 // Instead of per-BLAS trees plus a linear instance loop, every instance is baked into
 // world space (SPEC §2.5) and ONE tree is built over all triangles.
 //
-//   builder : binned SAH (16 bins / axis), leaves <= 4 triangles, depth-capped so the
-//             traversal stack has a hard bound (falls back to median splits).
-//   layout  : Node2 — each 64-byte node stores BOTH children's boxes, so one fetch
-//             decides two subtrees.  Leaves index a run of Woop-transformed triangles.
+//   builder : binned SAH (16 bins / axis) binary tree, leaves <= 3 triangles, depth-capped
+//             (falls back to median splits), then collapsed breadth-first into 8-wide nodes
+//             by repeatedly opening the child with the largest surface area.
+//   layout  : Node8 — 80-byte compressed wide node in the style of Ylitie, Karras & Laine,
+//             "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"
+//             (HPG 2017): child boxes quantised to 8 bits on a per-node power-of-two grid,
+//             children placed in octant-ordered slots so (slot XOR ray octant) is a
+//             front-to-back order, leaf children referencing runs of <= 3 Woop triangles.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -38,7 +42,7 @@ void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3],
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMax = 3;  // a leaf child of an 8-wide node carries at most 3 triangles
 constexpr uint32_t kMaxDepth = 30;  // traversal stack is sized from this
 
 struct Box {
@@ -212,16 +216,17 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
                 if (!std::isfinite(out.tri_verts[3 * (size_t)t + k].position[a]))
                     return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in baked triangle %u", t);
     if (n == 0) {
-        // a single node whose children can never be hit
-        Node2 root;
+        // a single node with eight empty slots: nothing can be hit
+        Node8 root;
         memset(&root, 0, sizeof root);
-        for (int a = 0; a < 3; ++a) { root.lo0[a] = root.lo1[a] = 1e30f; root.hi0[a] = root.hi1[a] = -1e30f; }
-        root.child0 = root.child1 = 0;
+        root.ex = root.ey = root.ez = 127;
+        memset(root.qlox, 255, 24);
         out.nodes.push_back(root);
         WoopTri z;
         memset(&z, 0, sizeof z);
         out.woop.push_back(z);
         out.leaf_prim.push_back(LPT_INVALID_INDEX);
+        out.max_depth = 1;
         return LPT_OK;
     }
     Builder b;
@@ -234,49 +239,125 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     }
     b.nodes.reserve(2 * (size_t)n);
     b.build(0, n, 0);
-    out.max_depth = b.max_depth;
 
-    // triangles in leaf order
-    out.woop.resize(n);
-    out.leaf_prim.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t p = b.refs[i].prim;
-        out.leaf_prim[i] = p;
-        const lpt_vertex *v = &out.tri_verts[3 * (size_t)p];
-        woop_from_triangle(v[0].position, v[1].position, v[2].position, out.woop[i]);
-    }
-    // Node2 layout: inner build nodes only; leaves become negative child references
-    std::vector<int32_t> remap(b.nodes.size(), -1);
-    int32_t n_inner = 0;
-    for (size_t i = 0; i < b.nodes.size(); ++i)
-        if (b.nodes[i].count == 0) remap[i] = n_inner++;
-    auto child_ref = [&](int32_t id) -> int32_t {
-        const BuildNode &c = b.nodes[id];
-        if (c.count) return ~(int32_t)((c.first << 2) | (c.count - 1u));
-        return remap[id];
-    };
-    if (n_inner == 0) {
-        // the root itself is a leaf: wrap it
-        Node2 root;
-        memset(&root, 0, sizeof root);
-        const BuildNode &r = b.nodes[0];
-        for (int a = 0; a < 3; ++a) { root.lo0[a] = r.box.lo[a]; root.hi0[a] = r.box.hi[a]; root.lo1[a] = 1e30f; root.hi1[a] = -1e30f; }
-        root.child0 = child_ref(0);
-        root.child1 = root.child0;
-        out.nodes.push_back(root);
-    } else {
-        out.nodes.resize((size_t)n_inner);
-        for (size_t i = 0; i < b.nodes.size(); ++i) {
-            if (remap[i] < 0) continue;
-            const BuildNode &bn = b.nodes[i];
-            Node2 &o = out.nodes[(size_t)remap[i]];
-            memset(&o, 0, sizeof o);
-            const BuildNode &l = b.nodes[bn.left], &r = b.nodes[bn.right];
-            for (int a = 0; a < 3; ++a) { o.lo0[a] = l.box.lo[a]; o.hi0[a] = l.box.hi[a]; o.lo1[a] = r.box.lo[a]; o.hi1[a] = r.box.hi[a]; }
-            o.child0 = child_ref(bn.left);
-            o.child1 = child_ref(bn.right);
+    // ---- collapse the binary tree into 8-wide nodes (breadth first, so siblings are adjacent)
+    struct Pending { int32_t bvh2; uint32_t depth; };
+    std::vector<Pending> queue;
+    queue.push_back({0, 1});
+    out.nodes.resize(1);
+    out.woop.reserve(n);
+    out.leaf_prim.reserve(n);
+    uint32_t max_depth = 1;
+    for (size_t w = 0; w < queue.size(); ++w) {
+        const int32_t root = queue[w].bvh2;
+        const uint32_t depth = queue[w].depth;
+        max_depth = std::max(max_depth, depth);
+        // children: open the inner member with the largest surface area until 8 (or none is left)
+        int32_t kids[8];
+        int nk = 0;
+        if (b.nodes[root].count) kids[nk++] = root;  // the whole tree is one leaf
+        else { kids[nk++] = b.nodes[root].left; kids[nk++] = b.nodes[root].right; }
+        while (nk < 8) {
+            int best = -1;
+            float best_area = -1.f;
+            for (int i = 0; i < nk; ++i)
+                if (!b.nodes[kids[i]].count) {
+                    const float a = b.nodes[kids[i]].box.half_area();
+                    if (a > best_area) { best_area = a; best = i; }
+                }
+            if (best < 0) break;
+            const int32_t open = kids[best];
+            kids[best] = b.nodes[open].left;
+            kids[nk++] = b.nodes[open].right;
         }
+        // node box = union of the children (they are padded already)
+        Box nb;
+        for (int i = 0; i < nk; ++i) nb.grow(b.nodes[kids[i]].box);
+        // slot assignment: slot s stands for the diagonal direction ds = (+-1,+-1,+-1) (bit set = +);
+        // greedily give every child the free slot its offset from the node centre points to most.
+        // Traversal visits slots in the order (slot XOR ray octant), i.e. roughly front to back.
+        int slot_of[8];
+        bool slot_used[8] = {false}, kid_done[8] = {false};
+        float cx[3];
+        for (int a = 0; a < 3; ++a) cx[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+        for (int round = 0; round < nk; ++round) {
+            float best = -1e30f;
+            int bi = 0, bs = 0;
+            for (int i = 0; i < nk; ++i) {
+                if (kid_done[i]) continue;
+                const Box &cb = b.nodes[kids[i]].box;
+                const float off[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cx[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cx[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cx[2]};
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (slot_used[sl]) continue;
+                    const float c = ((sl & 1) ? off[0] : -off[0]) + ((sl & 2) ? off[1] : -off[1]) + ((sl & 4) ? off[2] : -off[2]);
+                    if (c > best) { best = c; bi = i; bs = sl; }
+                }
+            }
+            kid_done[bi] = true;
+            slot_used[bs] = true;
+            slot_of[bi] = bs;
+        }
+        int kid_in_slot[8];
+        for (int sl = 0; sl < 8; ++sl) kid_in_slot[sl] = -1;
+        for (int i = 0; i < nk; ++i) kid_in_slot[slot_of[i]] = i;
+
+        Node8 node;
+        memset(&node, 0, sizeof node);
+        node.px = nb.lo[0]; node.py = nb.lo[1]; node.pz = nb.lo[2];
+        double scale[3];
+        uint8_t *eb[3] = {&node.ex, &node.ey, &node.ez};
+        for (int a = 0; a < 3; ++a) {
+            const double ext = (double)nb.hi[a] - (double)nb.lo[a];
+            int e = -126;
+            if (ext > 0.0) {
+                int k;
+                std::frexp(ext / 255.0, &k);  // ext/255 = m * 2^k, m in [0.5,1)  =>  255 * 2^k >= ext
+                e = std::min(std::max(k, -126), 127);
+            }
+            *eb[a] = (uint8_t)(e + 127);
+            scale[a] = std::ldexp(1.0, e);
+        }
+        node.child_base = (uint32_t)queue.size();
+        node.tri_base = (uint32_t)out.woop.size();
+        uint32_t tri_off = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            const int i = kid_in_slot[sl];
+            uint8_t *q[6] = {&node.qlox[sl], &node.qloy[sl], &node.qloz[sl], &node.qhix[sl], &node.qhiy[sl], &node.qhiz[sl]};
+            if (i < 0) {  // empty slot: inverted box, meta 0
+                *q[0] = *q[1] = *q[2] = 255;
+                *q[3] = *q[4] = *q[5] = 0;
+                continue;
+            }
+            const BuildNode &c = b.nodes[kids[i]];
+            for (int a = 0; a < 3; ++a) {
+                const double lo = std::floor(((double)c.box.lo[a] - (double)nb.lo[a]) / scale[a]);
+                const double hi = std::ceil(((double)c.box.hi[a] - (double)nb.lo[a]) / scale[a]);
+                *q[a] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
+                *q[3 + a] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
+            }
+            if (c.count) {
+                // leaf child: unary triangle count in the top 3 bits, offset from tri_base in the low 5
+                node.meta[sl] = (uint8_t)((((1u << c.count) - 1u) << 5) | tri_off);
+                for (uint32_t t = 0; t < c.count; ++t) {
+                    const uint32_t prim = b.refs[c.first + t].prim;
+                    const lpt_vertex *v = &out.tri_verts[3 * (size_t)prim];
+                    WoopTri wt;
+                    woop_from_triangle(v[0].position, v[1].position, v[2].position, wt);
+                    out.woop.push_back(wt);
+                    out.leaf_prim.push_back(prim);
+                }
+                tri_off += c.count;
+            } else {
+                node.meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
+                node.imask |= (uint8_t)(1u << sl);
+                queue.push_back({kids[i], depth + 1});
+            }
+        }
+        if (out.nodes.size() < queue.size()) out.nodes.resize(queue.size());
+        out.nodes[w] = node;
     }
+    out.max_depth = max_depth;
+    if (out.woop.size() != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %zu of %u triangles referenced", out.woop.size(), n);
     out.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return LPT_OK;
 }

@@ -38,13 +38,15 @@ struct lpt_scene {
 namespace lpt {
 
 // ---- baked, device-ready acceleration data (host copies) -------------------
-struct alignas(16) Node2 {  // 64 B: both children's boxes live in the parent
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t child0, child1;  // >=0 inner node; <0: leaf = ~((first << 2) | (count - 1))
-    int32_t pad[2];
+struct alignas(16) Node8 {  // 80 B compressed 8-wide node (five 16-byte loads)
+    float px, py, pz;            // origin of the node-local quantisation grid (= node box min)
+    uint8_t ex, ey, ez, imask;   // biased power-of-two grid step per axis; bit s of imask: slot s is an inner node
+    uint32_t child_base;         // index of the first inner child (inner children are contiguous, in slot order)
+    uint32_t tri_base;           // first triangle of this node's leaf children (<= 24, contiguous)
+    uint8_t meta[8];             // per slot: 0 empty | 0x20|(24+slot) inner | unary tri count<<5 | tri offset
+    uint8_t qlox[8], qloy[8], qloz[8], qhix[8], qhiy[8], qhiz[8];
 };
-static_assert(sizeof(Node2) == 64, "Node2 must be 64 bytes");
+static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
 struct alignas(16) WoopTri {  // 48 B world -> unit-triangle affine map
     float r0[4], r1[4], r2[4];
@@ -54,7 +56,7 @@ static_assert(sizeof(WoopTri) == 48, "WoopTri must be 48 bytes");
 struct Accel {
     std::vector<lpt_vertex> tri_verts;   // 3 per baked triangle (world space)
     std::vector<uint32_t> tri_material;  // per baked triangle
-    std::vector<Node2> nodes;            // node 0 = root
+    std::vector<Node8> nodes;            // node 0 = root
     std::vector<WoopTri> woop;           // in leaf order
     std::vector<uint32_t> leaf_prim;     // leaf slot -> baked triangle id
     uint32_t max_depth = 0;

@@ -86,6 +86,7 @@ struct lpt_renderer {
 };
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+static inline size_t stack_bytes(const DScene &sc) { return (size_t)sc.stack_entries * kTraceBlock * sizeof(uint2); }
 
 template <typename T>
 static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
@@ -200,7 +201,8 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
     hipError_t e = hipStreamSynchronize(s);  // host vectors die at scope exit
     if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
     DScene &d = sg->d;
-    d.nodes = (const DNode2 *)sg->nodes;
+    d.nodes = (const DNode8 *)sg->nodes;
+    d.stack_entries = acc.max_depth + 1u;
     d.woop = (const float4 *)sg->woop;
     d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     d.tri_verts = (const float4 *)sg->tri_verts;
@@ -216,7 +218,7 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
     d.n_images = (uint32_t)scene->images.size();
     sg->stats.triangles = d.n_tris;
     sg->stats.nodes = (uint32_t)acc.nodes.size();
-    sg->stats.node_bytes = (uint32_t)sizeof(Node2);
+    sg->stats.node_bytes = (uint32_t)sizeof(Node8);
     sg->stats.tri_bytes = (uint32_t)sizeof(WoopTri);
     sg->stats.max_depth = acc.max_depth;
     sg->stats.build_ms = acc.build_ms;
@@ -277,8 +279,8 @@ int lpt_trace_closest(lpt_device *dev, const lpt_scene_gpu *sg, const float *ori
     if (e == hipSuccess) e = hipMemcpyAsync(&ctr->qcount[0], &n, sizeof n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) {
         Queue q{dO, dD, nullptr};
-        const uint32_t blocks = div_up(n, kBlock);
-        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kBlock), 0, dev->stream, sg->d, q, dH, ctr, 0);
+        const uint32_t blocks = div_up(n, kTraceBlock);
+        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kTraceBlock), stack_bytes(sg->d), dev->stream, sg->d, q, dH, ctr, 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dH, sizeof(float4) * n, hipMemcpyDeviceToHost, dev->stream);
@@ -306,7 +308,7 @@ int lpt_trace_occluded(lpt_device *dev, const lpt_scene_gpu *sg, const float *or
     if (e == hipSuccess) e = hipMemcpyAsync(dO, o.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dD, d.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_query_occluded, dim3(div_up(n, kBlock)), dim3(kBlock), 0, dev->stream, sg->d, dO, dD, dR, n);
+        hipLaunchKernelGGL(k_query_occluded, dim3(div_up(n, kTraceBlock)), dim3(kTraceBlock), stack_bytes(sg->d), dev->stream, sg->d, dO, dD, dR, n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dR, n, hipMemcpyDeviceToHost, dev->stream);
@@ -588,7 +590,8 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
         HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 8u);
-        const uint32_t trace_blocks = div_up(p.n_slots, kBlock);  // covers the queue capacity; idle blocks exit
+        const uint32_t trace_blocks = div_up(p.n_slots, kTraceBlock);  // covers the queue capacity; idle waves exit
+        const size_t lds = stack_bytes(sc);
 
         // "ray generation" (:444-448)
         stage_begin(r, ST_RAYGEN);
@@ -606,15 +609,15 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
             seed += 1u;                          // :453, :487
             const Queue qin = r->q[b & 1u], qout = r->q[(b + 1u) & 1u];
             stage_begin(r, ST_INTERSECT);        // :457-464, :493-498
-            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, qin, r->hits, r->ctr, (int)b);
-            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, qin, r->hits, r->ctr, (int)b);
+            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b);
+            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b);
             stage_end(r);
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
             hipLaunchKernelGGL(k_shade, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed);
             stage_end(r);
             stage_begin(r, ST_SHADOW);
-            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kBlock), 0, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
+            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
             stage_end(r);
         }
         if (r->mode == LPT_BLIT_PATHTRACE || true) {

@@ -17,21 +17,23 @@
 namespace lptd {
 
 constexpr int kMaxBounces = 64;
-constexpr int kStackSize = 32;  // >= bvh.cpp kMaxDepth + 2
 constexpr int kBlock = 256;
-constexpr uint32_t kChunk = 512;  // rays a wave dequeues per atomic (8 packets of 64)
+constexpr int kTraceBlock = 64;  // traversal kernels: one wave per block, so LDS / slots free up per wave
 
-struct DNode2 {  // 64 B, mirrors lpt::Node2
-    float4 a;    // lo0.xyz, hi0.x
-    float4 b;    // hi0.yz, lo1.xy
-    float4 c;    // lo1.z, hi1.xyz
-    int child0, child1, pad0, pad1;
+// 80 B compressed 8-wide node, mirrors lpt::Node8 (common.h); read as five 16-byte loads
+struct DNode8 {
+    uint4 n0;  // px, py, pz (float bits), ex | ey<<8 | ez<<16 | imask<<24
+    uint4 n1;  // child_base, tri_base, meta[0..3], meta[4..7]
+    uint4 n2;  // qlo_x[0..3], qlo_x[4..7], qlo_y[0..3], qlo_y[4..7]
+    uint4 n3;  // qlo_z[0..3], qlo_z[4..7], qhi_x[0..3], qhi_x[4..7]
+    uint4 n4;  // qhi_y[0..3], qhi_y[4..7], qhi_z[0..3], qhi_z[4..7]
 };
 
 struct DImage { uint32_t offset, width, height, pad; };
 
 struct DScene {
-    const DNode2 *nodes;
+    const DNode8 *nodes;
+    uint32_t stack_entries;      // wide-tree depth + 1: per-lane traversal stack capacity (uint2 entries)
     const float4 *woop;          // 3 per leaf slot
     const uint32_t *leaf_prim;   // leaf slot -> baked triangle id
     const float4 *tri_verts;     // 6 per baked triangle: (pos,u)(nrm,v) x3
@@ -190,66 +192,101 @@ __device__ __forceinline__ float safe_inv(float d) {
     return fabsf(d) > 1.0e-30f ? 1.0f / d : copysignf(1.0e30f, d);
 }
 
-// Conservative slab test: [tn,tf] widened by a few ulp.  Box-vs-oracle agreement is not
-// required (only conservativeness); the triangle test decides the result.
-__device__ __forceinline__ bool slab(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, f3 inv, float tbest, float &tn) {
-    float t0x = (lx - o.x) * inv.x, t1x = (hx - o.x) * inv.x;
-    float t0y = (ly - o.y) * inv.y, t1y = (hy - o.y) * inv.y;
-    float t0z = (lz - o.z) * inv.z, t1z = (hz - o.z) * inv.z;
-    float nx = fminf(t0x, t1x), fx = fmaxf(t0x, t1x);
-    float ny = fminf(t0y, t1y), fy = fmaxf(t0y, t1y);
-    float nz = fminf(t0z, t1z), fz = fmaxf(t0z, t1z);
-    tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f)) * 0.9999996f;
-    float tf = fminf(fminf(fx, fy), fz) * 1.0000004f;
-    tf = fminf(tf, tbest);
-    return tn <= tf;
-}
-
-// One ray against the baked BVH.  ANY: stop at the first hit in (0, tmax].
-// `stack` points at this thread's column of the block's LDS stack (stride kBlock ints).
+// One ray against the compressed 8-wide BVH (layout: common.h Node8; traversal after Ylitie,
+// Karras & Laine, HPG 2017).  ANY: stop at the first hit in (0, tmax].
+//
+//  * a "node group" (base index, hit bits << 24 | imask) names the still-unvisited inner
+//    children of one node; a "triangle group" (tri base, 24 hit bits) its hit triangles.
+//    One 8-byte stack entry per tree level, kept in LDS (`stack` = this lane's column,
+//    stride kTraceBlock entries).
+//  * child boxes are decoded on the fly: t = q * (2^e / d) + (p - o) / d, near / far byte
+//    planes picked per axis from the ray's direction signs.  The [tn, tf] interval is widened
+//    by 4e-7 relative on both ends and triangle boxes are padded at build time, so the box
+//    tests are conservative; only the Woop test below decides hits (SPEC §7).
+//  * children sit in octant-ordered slots: visiting hit bits from the top after XOR-ing the
+//    slot with the inverted ray octant is an approximate front-to-back order.
 template <bool ANY, bool STATS>
-__device__ __forceinline__ bool traverse(const DScene &sc, f3 o, f3 d, float tmax, int *stack, Hit &best, uint32_t &n_nodes, uint32_t &n_tris) {
+__device__ __forceinline__ bool traverse(const DScene &sc, f3 o, f3 d, float tmax, uint2 *stack, Hit &best, uint32_t &n_nodes, uint32_t &n_tris) {
     best.t = tmax; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;
-    const f3 inv = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+    const uint32_t oinv = 7u - ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u));
+    const uint32_t oinv4 = oinv * 0x01010101u;
+    const float kNear = 0.9999996f, kFar = 1.0000004f;
+    uint2 ng = make_uint2(0u, 0x80000000u);  // the root, as the single hit child of a virtual parent
+    uint2 tg = make_uint2(0u, 0u);
     int sp = 0;
-    int cur = 0;  // root
     for (;;) {
-        if (cur >= 0) {
-            const DNode2 *n = sc.nodes + cur;
-            const float4 a = n->a, b = n->b, c = n->c;
-            const int c0 = n->child0, c1 = n->child1;
+        if (ng.y & 0xFF000000u) {
+            const uint32_t hits = ng.y;
+            const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
+            ng.y &= ~(1u << bit);
+            if (ng.y & 0xFF000000u) { stack[sp * kTraceBlock] = ng; sp++; }
+            const uint32_t slot = (bit - 24u) ^ oinv;
+            const uint32_t rel = (uint32_t)__popc(hits & ~(0xFFFFFFFFu << slot));  // inner children before `slot`
+            const DNode8 *n = sc.nodes + (ng.x + rel);
+            const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
             if (STATS) n_nodes++;
-            float tn0, tn1;
-            const bool h0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, best.t, tn0);
-            const bool h1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, o, inv, best.t, tn1);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                const int nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-                stack[sp * kBlock] = farc;
-                sp++;
-                cur = nearc;
-                continue;
-            }
-            if (h0) { cur = c0; continue; }
-            if (h1) { cur = c1; continue; }
-        } else {
-            const uint32_t ref = (uint32_t)(~cur);
-            const uint32_t first = ref >> 2, count = (ref & 3u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4 *w = sc.woop + 3u * (size_t)(first + i);
-                const float4 r0 = w[0], r1 = w[1], r2 = w[2];
-                if (STATS) n_tris++;
-                float t, u, v;
-                if (ray_triangle(r0, r1, r2, o, d, best.t, t, u, v)) {
-                    if (ANY) return true;
-                    const uint32_t prim = sc.leaf_prim[first + i];
-                    if (t < best.t || prim < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
+            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
+            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
+            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
+            const float by = (__uint_as_float(n0.y) - o.y) * iy;
+            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+            const float anx = ax * kNear, any_ = ay * kNear, anz = az * kNear, bnx = bx * kNear, bny = by * kNear, bnz = bz * kNear;
+            const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar, bfx = bx * kFar, bfy = by * kFar, bfz = bz * kFar;
+            uint32_t hitmask = 0u;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t meta4 = half ? n1.w : n1.z;
+                const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+                const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
+                const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
+                const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+                const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
+                const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
+                const uint32_t qnx = negx ? hix : lox, qfx = negx ? lox : hix;
+                const uint32_t qny = negy ? hiy : loy, qfy = negy ? loy : hiy;
+                const uint32_t qnz = negz ? hiz : loz, qfz = negz ? loz : hiz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sh = 8 * j;
+                    const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), anx, bnx);
+                    const float tny = fmaf((float)((qny >> sh) & 0xFFu), any_, bny);
+                    const float tnz = fmaf((float)((qnz >> sh) & 0xFFu), anz, bnz);
+                    const float tfx = fmaf((float)((qfx >> sh) & 0xFFu), afx, bfx);
+                    const float tfy = fmaf((float)((qfy >> sh) & 0xFFu), afy, bfy);
+                    const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), afz, bfz);
+                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+                    if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
                 }
             }
+            ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));
+            tg = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+        } else {
+            tg = ng;  // a postponed triangle group
+            ng = make_uint2(0u, 0u);
         }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * kBlock];
+        while (tg.y) {
+            const uint32_t k = (uint32_t)__ffs((int)tg.y) - 1u;
+            tg.y &= tg.y - 1u;
+            const uint32_t ti = tg.x + k;
+            const float4 *w = sc.woop + 3u * (size_t)ti;
+            const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+            if (STATS) n_tris++;
+            float t, u, v;
+            if (ray_triangle(r0, r1, r2, o, d, best.t, t, u, v)) {
+                if (ANY) return true;
+                const uint32_t prim = sc.leaf_prim[ti];
+                if (t < best.t || prim < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+            }
+        }
+        if (!(ng.y & 0xFF000000u)) {
+            if (sp == 0) break;
+            sp--;
+            ng = stack[sp * kTraceBlock];
+        }
     }
     return best.prim != 0xFFFFFFFFu;
 }
@@ -273,16 +310,18 @@ __device__ __forceinline__ void intersect_lights(const DScene &sc, f3 o, f3 d, H
     }
 }
 
+// dynamic LDS: sc.stack_entries * kTraceBlock uint2 (16-byte aligned, Guideline 17)
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
-    __shared__ int lds_stack[kStackSize * kBlock];
-    int *stack = lds_stack + threadIdx.x;
+__global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     const uint32_t count = ctr->qcount[bounce];
     uint32_t n_nodes = 0, n_tris = 0;
-    // static packets: block b owns rays [256 b, 256 b + 256); the grid covers the queue's
-    // capacity and blocks beyond the live count exit at once (no dequeue atomics: one
-    // device-scope word sustains only ~88 atomics/us, the hardware dispatcher is free)
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    // static packets: wave b owns rays [64 b, 64 b + 64); the grid covers the queue's capacity and
+    // waves beyond the live count exit at once (no dequeue atomics: one device-scope word
+    // sustains only ~88 atomics/us, the hardware dispatcher is free)
+    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < count; i += gridDim.x * kTraceBlock) {
         const float4 o4 = q.o[i], d4 = q.d[i];
         const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
         Hit h;
@@ -297,12 +336,11 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, Queue q, float4
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce) {
-    __shared__ int lds_stack[kStackSize * kBlock];
-    int *stack = lds_stack + threadIdx.x;
+__global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce) {
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     const uint32_t count = ctr->shcount[bounce];
     uint32_t n_nodes = 0, n_tris = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < count; i += gridDim.x * kTraceBlock) {
         const float4 o4 = sq.o[i], d4 = sq.d[i];
         Hit h;
         const bool occluded = traverse<true, STATS>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, n_nodes, n_tris);
@@ -585,9 +623,8 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float4 *accum, uchar4 
 }
 
 // stand-alone ray queries (lpt_trace_closest / lpt_trace_occluded)
-__global__ __launch_bounds__(kBlock) void k_query_occluded(DScene sc, const float4 *o, const float4 *d, uint8_t *out, uint32_t n) {
-    __shared__ int lds_stack[kStackSize * kBlock];
-    int *stack = lds_stack + threadIdx.x;
+__global__ __launch_bounds__(kTraceBlock) void k_query_occluded(DScene sc, const float4 *o, const float4 *d, uint8_t *out, uint32_t n) {
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 o4 = o[i], d4 = d[i];
