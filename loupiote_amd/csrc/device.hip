@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -62,6 +63,9 @@ struct lpt_renderer {
     float vfov = 0.78539816339744830962f;
     uint32_t rank = 0, world = 1, tile_w = 32, tile_h = 8;
     bool use_noise = false, stats = false, timings = false;
+    // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
+    int refill = 56;
+    uint32_t trace_waves_per_cu = 32;
     // device memory
     uint32_t n_slots = 0;
     uint32_t *n_slots_host = nullptr;  // pinned copy of n_slots (source of the async qcount[0] preset)
@@ -267,26 +271,20 @@ int lpt_trace_closest(lpt_device *dev, const lpt_scene_gpu *sg, const float *ori
         d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], -1.f);
     }
     float4 *dO = nullptr, *dD = nullptr, *dH = nullptr;
-    FrameCounters *ctr = nullptr;
     int st = LPT_OK;
     hipError_t e = hipMalloc(&dO, sizeof(float4) * n);
     if (e == hipSuccess) e = hipMalloc(&dD, sizeof(float4) * n);
     if (e == hipSuccess) e = hipMalloc(&dH, sizeof(float4) * n);
-    if (e == hipSuccess) e = hipMalloc(&ctr, sizeof(FrameCounters));
     if (e == hipSuccess) e = hipMemcpyAsync(dO, o.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dD, d.data(), sizeof(float4) * n, hipMemcpyHostToDevice, dev->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(ctr, 0, sizeof(FrameCounters), dev->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&ctr->qcount[0], &n, sizeof n, hipMemcpyHostToDevice, dev->stream);
     if (e == hipSuccess) {
-        Queue q{dO, dD, nullptr};
-        const uint32_t blocks = div_up(n, kTraceBlock);
-        hipLaunchKernelGGL(k_intersect<false>, dim3(blocks), dim3(kTraceBlock), stack_bytes(sg->d), dev->stream, sg->d, q, dH, ctr, 0);
+        hipLaunchKernelGGL(k_query_closest, dim3(div_up(n, kTraceBlock)), dim3(kTraceBlock), stack_bytes(sg->d), dev->stream, sg->d, dO, dD, dH, n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dH, sizeof(float4) * n, hipMemcpyDeviceToHost, dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
     if (e != hipSuccess) st = fail(LPT_ERR_HIP, "lpt_trace_closest: %s", hipGetErrorString(e));
-    hipFree(dO); hipFree(dD); hipFree(dH); hipFree(ctr);
+    hipFree(dO); hipFree(dD); hipFree(dH);
     return st;
 }
 
@@ -367,6 +365,8 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     HIP_TRY(hipSetDevice(dev->ordinal));
     lpt_renderer *r = new lpt_renderer();
     r->dev = dev;
+    if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
+    if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
     r->req_w = width; r->req_h = height;
     // get_downsampled_size (renderer.rs:18-22)
     r->w = (uint32_t)((float)width * r->downsample);
@@ -590,7 +590,7 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
         HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 8u);
-        const uint32_t trace_blocks = div_up(p.n_slots, kTraceBlock);  // covers the queue capacity; idle waves exit
+        const uint32_t trace_blocks = std::min<uint32_t>(div_up(p.n_slots, kTraceBlock), cus * r->trace_waves_per_cu);  // persistent waves
         const size_t lds = stack_bytes(sc);
 
         // "ray generation" (:444-448)
@@ -609,15 +609,15 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
             seed += 1u;                          // :453, :487
             const Queue qin = r->q[b & 1u], qout = r->q[(b + 1u) & 1u];
             stage_begin(r, ST_INTERSECT);        // :457-464, :493-498
-            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b);
-            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b);
+            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
+            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
             stage_end(r);
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
             hipLaunchKernelGGL(k_shade, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed);
             stage_end(r);
             stage_begin(r, ST_SHADOW);
-            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b);
+            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
             stage_end(r);
         }
         if (r->mode == LPT_BLIT_PATHTRACE || true) {

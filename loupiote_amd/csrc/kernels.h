@@ -55,8 +55,10 @@ struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w =
 struct FrameCounters {
     uint32_t qcount[kMaxBounces + 1];
     uint32_t shcount[kMaxBounces];
-    uint32_t ihead[kMaxBounces];
-    uint32_t shead[kMaxBounces];
+    // chunk heads: 8 per bounce (one per XCD), each on its own 128-byte line so that the atomics of
+    // different heads do not serialise on one L2 line
+    uint32_t ihead[kMaxBounces * 8 * 32];
+    uint32_t shead[kMaxBounces * 8 * 32];
     uint32_t shaded[kMaxBounces];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
 };
@@ -205,90 +207,145 @@ __device__ __forceinline__ float safe_inv(float d) {
 //    tests are conservative; only the Woop test below decides hits (SPEC §7).
 //  * children sit in octant-ordered slots: visiting hit bits from the top after XOR-ing the
 //    slot with the inverted ray octant is an approximate front-to-back order.
+// Per-lane traversal state: one step() = at most one node visit plus one triangle test, so a
+// wave can interleave lanes that are in different phases and refill lanes whose ray is done.
+struct RayState {
+    f3 o, d;
+    float ix, iy, iz;
+    uint32_t oinv;
+    Hit best;
+    uint2 ng, tg;
+    int sp;
+};
+
+__device__ __forceinline__ void ray_begin(RayState &rs, f3 o, f3 d, float tmax) {
+    rs.o = o; rs.d = d;
+    rs.ix = safe_inv(d.x); rs.iy = safe_inv(d.y); rs.iz = safe_inv(d.z);
+    rs.oinv = 7u - ((rs.ix < 0.0f ? 1u : 0u) | (rs.iy < 0.0f ? 2u : 0u) | (rs.iz < 0.0f ? 4u : 0u));
+    rs.best.t = tmax; rs.best.u = 0.f; rs.best.v = 0.f; rs.best.prim = 0xFFFFFFFFu;
+    rs.ng = make_uint2(0u, 0x80000000u);  // the root, as the single hit child of a virtual parent
+    rs.tg = make_uint2(0u, 0u);
+    rs.sp = 0;
+}
+
+// returns true when the ray is finished (ANY: also as soon as something is hit; best.prim != ~0 then)
 template <bool ANY, bool STATS>
-__device__ __forceinline__ bool traverse(const DScene &sc, f3 o, f3 d, float tmax, uint2 *stack, Hit &best, uint32_t &n_nodes, uint32_t &n_tris) {
-    best.t = tmax; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;
-    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
-    const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
-    const uint32_t oinv = 7u - ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u));
-    const uint32_t oinv4 = oinv * 0x01010101u;
-    const float kNear = 0.9999996f, kFar = 1.0000004f;
-    uint2 ng = make_uint2(0u, 0x80000000u);  // the root, as the single hit child of a virtual parent
-    uint2 tg = make_uint2(0u, 0u);
-    int sp = 0;
-    for (;;) {
-        if (ng.y & 0xFF000000u) {
-            const uint32_t hits = ng.y;
-            const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
-            ng.y &= ~(1u << bit);
-            if (ng.y & 0xFF000000u) { stack[sp * kTraceBlock] = ng; sp++; }
-            const uint32_t slot = (bit - 24u) ^ oinv;
-            const uint32_t rel = (uint32_t)__popc(hits & ~(0xFFFFFFFFu << slot));  // inner children before `slot`
-            const DNode8 *n = sc.nodes + (ng.x + rel);
-            const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
-            if (STATS) n_nodes++;
-            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
-            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
-            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
-            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
-            const float by = (__uint_as_float(n0.y) - o.y) * iy;
-            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
-            const float anx = ax * kNear, any_ = ay * kNear, anz = az * kNear, bnx = bx * kNear, bny = by * kNear, bnz = bz * kNear;
-            const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar, bfx = bx * kFar, bfy = by * kFar, bfz = bz * kFar;
-            uint32_t hitmask = 0u;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const uint32_t meta4 = half ? n1.w : n1.z;
-                const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-                const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
-                const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
-                const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-                const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
-                const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
-                const uint32_t qnx = negx ? hix : lox, qfx = negx ? lox : hix;
-                const uint32_t qny = negy ? hiy : loy, qfy = negy ? loy : hiy;
-                const uint32_t qnz = negz ? hiz : loz, qfz = negz ? loz : hiz;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int sh = 8 * j;
-                    const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), anx, bnx);
-                    const float tny = fmaf((float)((qny >> sh) & 0xFFu), any_, bny);
-                    const float tnz = fmaf((float)((qnz >> sh) & 0xFFu), anz, bnz);
-                    const float tfx = fmaf((float)((qfx >> sh) & 0xFFu), afx, bfx);
-                    const float tfy = fmaf((float)((qfy >> sh) & 0xFFu), afy, bfy);
-                    const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), afz, bfz);
-                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-                    if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
-                }
-            }
-            ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));
-            tg = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
-        } else {
-            tg = ng;  // a postponed triangle group
-            ng = make_uint2(0u, 0u);
+__device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *stack, uint32_t &n_nodes, uint32_t &n_tris) {
+    if (rs.tg.y == 0u) {
+        if (!(rs.ng.y & 0xFF000000u)) {
+            if (rs.sp == 0) return true;
+            rs.sp--;
+            rs.ng = stack[rs.sp * kTraceBlock];
         }
-        while (tg.y) {
-            const uint32_t k = (uint32_t)__ffs((int)tg.y) - 1u;
-            tg.y &= tg.y - 1u;
-            const uint32_t ti = tg.x + k;
-            const float4 *w = sc.woop + 3u * (size_t)ti;
-            const float4 r0 = w[0], r1 = w[1], r2 = w[2];
-            if (STATS) n_tris++;
-            float t, u, v;
-            if (ray_triangle(r0, r1, r2, o, d, best.t, t, u, v)) {
-                if (ANY) return true;
-                const uint32_t prim = sc.leaf_prim[ti];
-                if (t < best.t || prim < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+        const uint32_t hits = rs.ng.y;
+        const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
+        rs.ng.y &= ~(1u << bit);
+        if (rs.ng.y & 0xFF000000u) { stack[rs.sp * kTraceBlock] = rs.ng; rs.sp++; }
+        const uint32_t slot = (bit - 24u) ^ rs.oinv;
+        const uint32_t rel = (uint32_t)__popc(hits & ~(0xFFFFFFFFu << slot));  // inner children before `slot`
+        const DNode8 *n = sc.nodes + (rs.ng.x + rel);
+        const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
+        if (STATS) n_nodes++;
+        const float kNear = 0.9999996f, kFar = 1.0000004f;
+        const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;
+        const uint32_t oinv4 = rs.oinv * 0x01010101u;
+        const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * rs.ix;
+        const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rs.iy;
+        const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rs.iz;
+        const float bx = (__uint_as_float(n0.x) - rs.o.x) * rs.ix;
+        const float by = (__uint_as_float(n0.y) - rs.o.y) * rs.iy;
+        const float bz = (__uint_as_float(n0.z) - rs.o.z) * rs.iz;
+        const float anx = ax * kNear, any_ = ay * kNear, anz = az * kNear, bnx = bx * kNear, bny = by * kNear, bnz = bz * kNear;
+        const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar, bfx = bx * kFar, bfy = by * kFar, bfz = bz * kFar;
+        const float tbest = rs.best.t;
+        uint32_t hitmask = 0u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t meta4 = half ? n1.w : n1.z;
+            const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+            const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
+            const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
+            const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+            const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
+            const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
+            const uint32_t qnx = negx ? hix : lox, qfx = negx ? lox : hix;
+            const uint32_t qny = negy ? hiy : loy, qfy = negy ? loy : hiy;
+            const uint32_t qnz = negz ? hiz : loz, qfz = negz ? loz : hiz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sh = 8 * j;
+                const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), anx, bnx);
+                const float tny = fmaf((float)((qny >> sh) & 0xFFu), any_, bny);
+                const float tnz = fmaf((float)((qnz >> sh) & 0xFFu), anz, bnz);
+                const float tfx = fmaf((float)((qfx >> sh) & 0xFFu), afx, bfx);
+                const float tfy = fmaf((float)((qfy >> sh) & 0xFFu), afy, bfy);
+                const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), afz, bfz);
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
+                if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
             }
         }
-        if (!(ng.y & 0xFF000000u)) {
-            if (sp == 0) break;
-            sp--;
-            ng = stack[sp * kTraceBlock];
+        rs.ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));
+        rs.tg = make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+    }
+    if (rs.tg.y) {
+        const uint32_t k = (uint32_t)__ffs((int)rs.tg.y) - 1u;
+        rs.tg.y &= rs.tg.y - 1u;
+        const uint32_t ti = rs.tg.x + k;
+        const float4 *w = sc.woop + 3u * (size_t)ti;
+        const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+        if (STATS) n_tris++;
+        float t, u, v;
+        if (ray_triangle(r0, r1, r2, rs.o, rs.d, rs.best.t, t, u, v)) {
+            const uint32_t prim = sc.leaf_prim[ti];
+            if (t < rs.best.t || prim < rs.best.prim) { rs.best.t = t; rs.best.u = u; rs.best.v = v; rs.best.prim = prim; }
+            if (ANY) return true;
         }
     }
+    return false;
+}
+
+// one ray start to finish (stand-alone queries)
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool traverse(const DScene &sc, f3 o, f3 d, float tmax, uint2 *stack, Hit &best, uint32_t &n_nodes, uint32_t &n_tris) {
+    RayState rs;
+    ray_begin(rs, o, d, tmax);
+    while (!ray_step<ANY, STATS>(sc, rs, stack, n_nodes, n_tris)) {}
+    best = rs.best;
     return best.prim != 0xFFFFFFFFu;
+}
+
+// Work distribution of the persistent traversal kernels.  The queue is cut into chunks of
+// `chunk` rays (64..256); chunk c belongs to head c % 8 and a wave only ever pulls from head
+// blockIdx % 8 (block b runs on XCD b % 8 in practice, so each XCD drains its own head; the
+// mapping only matters for speed).  A pull is ONE returning atomic by lane 0 per chunk — about
+// 1K atomics per head for a 2M-ray queue, far below the ~88 atomics/us a single word sustains.
+struct ChunkPuller {
+    uint32_t *head;
+    uint32_t count, chunk, n_chunks, home;
+    uint32_t next, end;
+    bool dry;
+};
+__device__ __forceinline__ void puller_init(ChunkPuller &p, uint32_t *heads8, uint32_t count) {
+    p.home = blockIdx.x & 7u;
+    p.head = heads8 + p.home * 32u;
+    p.count = count;
+    const uint32_t per_wave = count / (2u * 64u * max(gridDim.x, 1u));  // aim at >= 2 chunks per wave
+    p.chunk = 64u * min(max(per_wave, 1u), 4u);
+    p.n_chunks = (count + p.chunk - 1u) / p.chunk;
+    p.next = p.end = 0u;
+    p.dry = false;
+}
+// wave-uniform: make [next,end) non-empty if any chunk is left for this wave's head
+__device__ __forceinline__ void puller_pull(ChunkPuller &p) {
+    if (p.next < p.end || p.dry) return;
+    uint32_t k = 0;
+    if ((threadIdx.x & 63u) == 0) k = atomicAdd(p.head, 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t c = p.home + 8u * k;
+    if (c >= p.n_chunks) { p.dry = true; return; }
+    p.next = c * p.chunk;
+    p.end = min(p.count, p.next + p.chunk);
 }
 
 // SPEC §8: rectangular emitters (front face only, strictly closer than any triangle)
@@ -313,21 +370,41 @@ __device__ __forceinline__ void intersect_lights(const DScene &sc, f3 o, f3 d, H
 // dynamic LDS: sc.stack_entries * kTraceBlock uint2 (16-byte aligned, Guideline 17)
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
 
+// Persistent traversal: a fixed grid of waves, each owning a contiguous slice of the queue.
+// Whenever `refill` or fewer lanes still carry a live ray, the idle lanes pull the next rays of
+// the wave's own slice (a ballot + prefix count; no atomics), so lanes whose ray ended early
+// do not idle while the longest ray of the packet finishes.
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
+__global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, int refill) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
-    const uint32_t count = ctr->qcount[bounce];
+    ChunkPuller pl;
+    puller_init(pl, &ctr->ihead[bounce * 8 * 32], ctr->qcount[bounce]);
+    const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
-    // static packets: wave b owns rays [64 b, 64 b + 64); the grid covers the queue's capacity and
-    // waves beyond the live count exit at once (no dequeue atomics: one device-scope word
-    // sustains only ~88 atomics/us, the hardware dispatcher is free)
-    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < count; i += gridDim.x * kTraceBlock) {
-        const float4 o4 = q.o[i], d4 = q.d[i];
-        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-        Hit h;
-        traverse<false, STATS>(sc, o, d, LPT_T_INF, stack, h, n_nodes, n_tris);
-        intersect_lights(sc, o, d, h);
-        hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+    RayState rs;
+    bool active = false;
+    uint32_t ray = 0;
+    for (;;) {
+        const unsigned long long amask = __ballot(active);
+        const int n_active = __popcll(amask);
+        if (n_active <= refill) {
+            puller_pull(pl);
+            if (pl.next < pl.end) {
+                const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
+                if (!active && idx < pl.end) {
+                    const float4 o4 = q.o[idx], d4 = q.d[idx];
+                    ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), LPT_T_INF);
+                    ray = idx;
+                    active = true;
+                }
+                pl.next = min(pl.end, pl.next + (uint32_t)(64 - n_active));
+            } else if (n_active == 0) break;
+        }
+        if (active && ray_step<false, STATS>(sc, rs, stack, n_nodes, n_tris)) {
+            intersect_lights(sc, rs.o, rs.d, rs.best);
+            hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
+            active = false;
+        }
     }
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
@@ -336,26 +413,60 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, f
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce) {
+__global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce, int refill) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
-    const uint32_t count = ctr->shcount[bounce];
+    ChunkPuller pl;
+    puller_init(pl, &ctr->shead[bounce * 8 * 32], ctr->shcount[bounce]);
+    const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
-    for (uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x; i < count; i += gridDim.x * kTraceBlock) {
-        const float4 o4 = sq.o[i], d4 = sq.d[i];
-        Hit h;
-        const bool occluded = traverse<true, STATS>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, n_nodes, n_tris);
-        if (!occluded) {
-            const uint32_t slot = __float_as_uint(d4.w);
-            const float4 c = sq.c[i];
-            float4 L = Lsum[slot];
-            L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
-            Lsum[slot] = L;
+    RayState rs;
+    bool active = false;
+    uint32_t ray = 0;
+    for (;;) {
+        const unsigned long long amask = __ballot(active);
+        const int n_active = __popcll(amask);
+        if (n_active <= refill) {
+            puller_pull(pl);
+            if (pl.next < pl.end) {
+                const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
+                if (!active && idx < pl.end) {
+                    const float4 o4 = sq.o[idx], d4 = sq.d[idx];
+                    ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w);
+                    ray = idx;
+                    active = true;
+                }
+                pl.next = min(pl.end, pl.next + (uint32_t)(64 - n_active));
+            } else if (n_active == 0) break;
+        }
+        if (active && ray_step<true, STATS>(sc, rs, stack, n_nodes, n_tris)) {
+            if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
+                const uint32_t slot = __float_as_uint(sq.d[ray].w);
+                const float4 c = sq.c[ray];
+                float4 L = Lsum[slot];
+                L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+                Lsum[slot] = L;
+            }
+            active = false;
         }
     }
     if (STATS) {
         atomicAdd(&ctr->shadow_nodes, (unsigned long long)n_nodes);
         atomicAdd(&ctr->shadow_tris, (unsigned long long)n_tris);
     }
+}
+
+// stand-alone closest-hit query (lpt_trace_closest): one ray per lane, no refill
+__global__ __launch_bounds__(kTraceBlock) void k_query_closest(DScene sc, const float4 *o, const float4 *d, float4 *hits, uint32_t n) {
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 o4 = o[i], d4 = d[i];
+    const f3 oo = mk3(o4.x, o4.y, o4.z), dd = mk3(d4.x, d4.y, d4.z);
+    Hit h;
+    uint32_t a = 0, b = 0;
+    traverse<false, false>(sc, oo, dd, LPT_T_INF, stack, h, a, b);
+    intersect_lights(sc, oo, dd, h);
+    hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
 }
 
 // ------------------------------------------------------------------ SPEC §9 textures / environment
