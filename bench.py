@@ -5,7 +5,7 @@ Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponz
   synthetic_atrium(seed=2) — the Sponza STAND-IN (the real asset is absent) —
   1920x1080, 4 spp (= 4 raytrace() calls with accumulate), path depth 8, camera = the reference's
   start pose.  One "step" = one such frame: reset_accumulation(); accumulate=true;
-  4 x Renderer::raytrace(view); for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
+  4 x Renderer::raytrace(view) — issued as lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
   Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
   N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
   N grows ("strong" scaling of one frame).
@@ -60,13 +60,20 @@ def cpu_baseline(desc, view, threads):
 
 
 def main():
+    global WIDTH, HEIGHT, SPP
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default="atrium")
+    ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
+    WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
+    BATCH = not args.no_batch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,8 +108,11 @@ def main():
     def step():
         r.reset_accumulation()
         r.accumulate = True
-        for _ in range(SPP):
-            r.raytrace(view)
+        if BATCH:
+            r.raytrace_n(view, SPP)      # == SPP x { raytrace(view); accumulate = true } as one wavefront
+        else:
+            for _ in range(SPP):
+                r.raytrace(view)
         if world > 1:
             # radiance reduce over xGMI: ordered after the renderer's stream, which the next
             # frame's kernels in turn wait on (torch issues the RCCL op relative to `ext`)
@@ -181,7 +191,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in, 262144 tris], 1920x1080, 4 spp, depth 8, "
-                                   "camera (-10,1,0)->(1,0.35,0); step = 1 frame (4 x raytrace + reduce)",
+                                   "camera (-10,1,0)->(1,0.35,0); step = 1 frame (raytrace_n(view,4) == 4 x raytrace, + reduce)",
                        "tiles": "32x8 interleaved, tile_id mod N", "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
             "ms_per_frame": elapsed / args.steps * 1e3,

@@ -274,6 +274,11 @@ int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg,
  * (crates/standalone/src/camera.rs:101-108).  Returns LPT_OK and does nothing
  * when resources are unset (renderer.rs:403-407,419-422). */
 int lpt_renderer_raytrace(lpt_renderer *r, const float view_transform[16]);
+/* Build-only batching of the call above: exactly equivalent (bit for bit) to
+ * n x { lpt_renderer_raytrace(r, view); accumulate = true (app.rs:318); } but traced as ONE wavefront
+ * of n samples per pixel (sample-major queues), which keeps the persistent traversal waves fed.
+ * Seeds advance by max_bounces per sample and samples are accumulated in call order.  1 <= n <= 64. */
+int lpt_renderer_raytrace_n(lpt_renderer *r, const float view_transform[16], uint32_t n_samples);
 /* replaces: Renderer::reset_accumulation (renderer.rs:609-618) */
 int lpt_renderer_reset_accumulation(lpt_renderer *r);
 /* replaces: pub accumulate (renderer.rs:204; set by the app at app.rs:318) */

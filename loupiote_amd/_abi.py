@@ -98,6 +98,7 @@ SIGNATURES = {
     "lpt_max_per_pixel_bytes": (_u32, []),
     "lpt_renderer_set_resources": (_i, [_vp, _vp, _vp]),
     "lpt_renderer_raytrace": (_i, [_vp, _vp]),
+    "lpt_renderer_raytrace_n": (_i, [_vp, _vp, _u32]),
     "lpt_renderer_reset_accumulation": (_i, [_vp]),
     "lpt_renderer_set_accumulate": (_i, [_vp, _i]),
     "lpt_renderer_get_accumulate": (_i, [_vp, C.POINTER(_i)]),

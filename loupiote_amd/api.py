@@ -294,6 +294,11 @@ class Renderer:
         m = np.ascontiguousarray(view_transform, np.float32).reshape(16)
         _check(A.lib().lpt_renderer_raytrace(self._h, A.ptr(m)))
 
+    def raytrace_n(self, view_transform, n_samples):
+        """build-only: n x { raytrace(view); accumulate = true } as one wavefront (bit-identical result)"""
+        m = np.ascontiguousarray(view_transform, np.float32).reshape(16)
+        _check(A.lib().lpt_renderer_raytrace_n(self._h, A.ptr(m), int(n_samples)))
+
     def reset_accumulation(self):
         _check(A.lib().lpt_renderer_reset_accumulation(self._h))
 

@@ -68,7 +68,9 @@ struct lpt_renderer {
     uint32_t trace_waves_per_cu = 32;
     // device memory
     uint32_t n_slots = 0;
-    uint32_t *n_slots_host = nullptr;  // pinned copy of n_slots (source of the async qcount[0] preset)
+    uint32_t batch_cap = 1;            // samples per pixel the per-ray buffers can hold (raytrace_n)
+    uint32_t *n_slots_host = nullptr;  // pinned ring of dense ray counts (source of the async qcount[0] preset)
+    uint32_t n_slots_ring = 0;
     Queue q[2]{};
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr, *accum = nullptr, *scratch = nullptr;
@@ -333,15 +335,14 @@ static void shard_geometry(const lpt_renderer *r, uint32_t &tiles_x, uint32_t &n
     n_slots = owned * r->tile_w * r->tile_h;
 }
 
-static int alloc_frame_buffers(lpt_renderer *r) {
-    HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
-    free_frame_buffers(r);
-    if (!r->w || !r->h) return LPT_OK;
-    uint32_t tiles_x, n_tiles, n_slots;
-    shard_geometry(r, tiles_x, n_tiles, n_slots);
-    const size_t n = n_slots ? n_slots : 64;
-    const size_t px = (size_t)r->w * r->h;
+// per-ray buffers (queues, hits, shadow queue, per-sample radiance): n_slots * batch_cap elements
+static int alloc_ray_buffers(lpt_renderer *r) {
+    void *ptrs[] = {r->q[0].o, r->q[0].d, r->q[0].T, r->q[1].o, r->q[1].d, r->q[1].T, r->sq.o, r->sq.d, r->sq.c, r->hits, r->Lsum};
+    for (void *p : ptrs) if (p) hipFree(p);
+    r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
+    r->hits = r->Lsum = nullptr;
+    const size_t n = std::max<size_t>((size_t)r->n_slots * r->batch_cap, 64);
+    if (n > 0x7FFFFFFFull) return fail(LPT_ERR_INVALID_ARG, "batch of %u samples x %u pixel slots exceeds 2^31 rays", r->batch_cap, r->n_slots);
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&r->q[k].o, sizeof(float4) * n));
         HIP_TRY(hipMalloc(&r->q[k].d, sizeof(float4) * n));
@@ -352,11 +353,23 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     HIP_TRY(hipMalloc(&r->sq.c, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&r->hits, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&r->Lsum, sizeof(float4) * n));
+    return LPT_OK;
+}
+
+static int alloc_frame_buffers(lpt_renderer *r) {
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    free_frame_buffers(r);
+    if (!r->w || !r->h) return LPT_OK;
+    uint32_t tiles_x, n_tiles, n_slots;
+    shard_geometry(r, tiles_x, n_tiles, n_slots);
+    const size_t px = (size_t)r->w * r->h;
+    r->n_slots = n_slots;
+    int st = alloc_ray_buffers(r);
+    if (st != LPT_OK) return st;
     HIP_TRY(hipMalloc(&r->accum, sizeof(float4) * px));
     HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
     HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->dev->stream));
-    r->n_slots = n_slots;
-    *r->n_slots_host = n_slots;
     return LPT_OK;
 }
 
@@ -374,7 +387,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     hipError_t e = hipMalloc(&r->ctr, sizeof(FrameCounters));
     if (e == hipSuccess) e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, 64 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
     if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
     if (e != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e)); }
@@ -556,9 +569,12 @@ static inline void stage_end(lpt_renderer *r) {
     r->ev_count[slot]++;
 }
 
-int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
+int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) { return lpt_renderer_raytrace_n(r, view, 1u); }
+
+int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_samples) {
     if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
-    r->frame_back = !r->frame_back;              // renderer.rs:401
+    if (n_samples == 0u || n_samples > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace_n: n must be in [1,64]");
+    if (n_samples & 1u) r->frame_back = !r->frame_back;   // renderer.rs:401, once per emulated call
     if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
     if (!r->w || !r->h) return LPT_OK;
     HIP_TRY(hipSetDevice(r->dev->ordinal));
@@ -580,6 +596,15 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
     p.frame_count = r->frame_count;
     p.max_bounces = nb;
+    p.n_samples = n_samples;
+    p.fc_inc0 = r->accumulate ? 1u : 0u;
+    if (n_samples > r->batch_cap && p.n_slots) {
+        HIP_TRY(hipStreamSynchronize(s));
+        r->batch_cap = n_samples;
+        int st = alloc_ray_buffers(r);
+        if (st != LPT_OK) return st;
+    }
+    const uint32_t n_rays = p.n_slots * n_samples;
 
     DProbe probe = r->probe ? r->probe->d : DProbe{(const uint8_t *)r->default_probe, 1u, 1u};
     DNoise nz{(const uint8_t *)r->noise, r->noise_w, r->noise_h, (r->use_noise && r->noise) ? 1u : 0u};
@@ -589,15 +614,17 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
     if (p.n_slots) {
         HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
-        const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots, kBlock), cus * 8u);
-        const uint32_t trace_blocks = std::min<uint32_t>(div_up(p.n_slots, kTraceBlock), cus * r->trace_waves_per_cu);  // persistent waves
+        const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
+        const uint32_t trace_blocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), cus * r->trace_waves_per_cu);  // persistent waves
         const size_t lds = stack_bytes(sc);
 
         // "ray generation" (:444-448)
         stage_begin(r, ST_RAYGEN);
         const bool dense = (r->w % r->tile_w == 0u) && (r->h % r->tile_h == 0u);
         if (dense) {
-            HIP_TRY(hipMemcpyAsync(&r->ctr->qcount[0], r->n_slots_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            uint32_t *src = r->n_slots_host + (r->n_slots_ring++ & 63u);  // pinned; stays valid until the copy has run
+            *src = n_rays;
+            HIP_TRY(hipMemcpyAsync(&r->ctr->qcount[0], src, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_raygen<true>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
         } else {
             hipLaunchKernelGGL(k_raygen<false>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
@@ -629,8 +656,11 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
         hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, s, r->ctr, r->totals, nb);
         HIP_TRY(hipGetLastError());
     }
-    r->seed += nb;                               // seed += 1 per intersect stage, never reset
-    if (r->accumulate) r->frame_count += 1u;     // :535-537
+    // bookkeeping of n emulated calls: { raytrace(); accumulate = true (app.rs:318); } x n
+    r->seed += nb * n_samples;                   // seed += 1 per intersect stage, never reset
+    if (r->accumulate) r->frame_count += 1u;     // :535-537 for the first call
+    r->frame_count += n_samples - 1u;            // later calls run with accumulate == true
+    if (n_samples > 1u) r->accumulate = true;
     return LPT_OK;
 }
 

@@ -71,6 +71,10 @@ struct FrameParams {
     uint32_t user_seed, seed_counter;
     uint32_t rank, world, tile_w, tile_h, tiles_x, n_tiles, n_slots;
     uint32_t frame_count, max_bounces;
+    // batched samples (lpt_renderer_raytrace_n): sample k of the batch behaves like the k-th of n
+    // consecutive raytrace() calls: seeds advance by max_bounces per sample, frame_count by fc_inc0
+    // after the first sample and by 1 after every later one.  Virtual slot = sample * n_slots + slot.
+    uint32_t n_samples, fc_inc0;
 };
 
 // pixel slot -> pixel.  Slots enumerate this rank's tiles (tile ids rank, rank+world, ...)
@@ -141,16 +145,19 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
     __shared__ uint32_t lds[8];
     const uint32_t stride = gridDim.x * blockDim.x;
     // n_slots is a multiple of 256 (tile area is), so whole blocks stay converged for the barriers
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+    const uint32_t total = p.n_slots * p.n_samples;
+    for (uint32_t vslot = blockIdx.x * blockDim.x + threadIdx.x; vslot < total; vslot += stride) {
+        const uint32_t sample = vslot / p.n_slots, slot = vslot - sample * p.n_slots;
+        const uint32_t seed_counter = p.seed_counter + sample * p.max_bounces;
         uint32_t x = 0, y = 0;
         const bool valid = slot_to_pixel(p, slot, x, y);
-        Lsum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Lsum[vslot] = make_float4(0.f, 0.f, 0.f, 0.f);
         f3 d = mk3(0.f, 0.f, 0.f);
         if (valid) {
             const uint32_t pixel = y * p.width + x;
-            Rng r = rng_init(pixel, stage_seed(p.user_seed, p.seed_counter), LPT_TAG_RAYGEN);
+            Rng r = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_RAYGEN);
             float jx = rng_next(r), jy = rng_next(r);
-            noise_shift(nz, x, y, p.seed_counter, jx, jy);
+            noise_shift(nz, x, y, seed_counter, jx, jy);
             float sx = ((float)x + jx) / (float)p.width;
             float sy = ((float)y + jy) / (float)p.height;
             float cx = (2.0f * sx - 1.0f) * p.ax;
@@ -159,9 +166,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
                          (p.right.z * cx + p.up.z * cy) + p.fwd.z);
             d = normalize(dir);
         }
-        const uint32_t idx = DENSE ? slot : block_compact(valid, &ctr->qcount[0], lds);
+        const uint32_t idx = DENSE ? vslot : block_compact(valid, &ctr->qcount[0], lds);
         if (valid) {
-            q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(slot));
+            q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(vslot));
             q.d[idx] = make_float4(d.x, d.y, d.z, -1.0f);
             q.T[idx] = make_float4(1.f, 1.f, 1.f, 0.f);
         }
@@ -534,7 +541,7 @@ __device__ __forceinline__ f3 env_lookup(const DProbe &pr, f3 d) {
 // ------------------------------------------------------------------ shading (SPEC §12)
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
-                                                  uint32_t seed_counter) {
+                                                  uint32_t seed_base) {
     __shared__ uint32_t lds[8];
     const uint32_t count = ctr->qcount[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -612,8 +619,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
                     const float pspec = spec_probability(sf, NoV);
                     uint32_t x = 0, y = 0;
-                    slot_to_pixel(p, slot, x, y);
+                    const uint32_t sample = slot / p.n_slots;
+                    slot_to_pixel(p, slot - sample * p.n_slots, x, y);
                     const uint32_t pixel = y * p.width + x;
+                    const uint32_t seed_counter = seed_base + sample * p.max_bounces;
                     Rng rg = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_SHADE);
                     float r0 = rng_next(rg), r1 = rng_next(rg), r2 = rng_next(rg);
                     float r3 = rng_next(rg), r4 = rng_next(rg), r5 = rng_next(rg);
@@ -694,14 +703,16 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
         uint32_t x, y;
         if (!slot_to_pixel(p, slot, x, y)) continue;
-        const float4 L = Lsum[slot];
         const size_t px = (size_t)y * p.width + x;
-        if (p.frame_count == 1u) accum[px] = make_float4(L.x, L.y, L.z, 1.0f);
-        else {
-            float4 a = accum[px];
-            a.x = a.x + L.x; a.y = a.y + L.y; a.z = a.z + L.z; a.w = a.w + 1.0f;
-            accum[px] = a;
+        uint32_t fc = p.frame_count;
+        float4 a = fc == 1u ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[px];
+        for (uint32_t k = 0; k < p.n_samples; ++k) {  // in call order: the fp32 sums are order-sensitive
+            const float4 L = Lsum[(size_t)k * p.n_slots + slot];
+            if (fc == 1u) a = make_float4(L.x, L.y, L.z, 1.0f);
+            else { a.x = a.x + L.x; a.y = a.y + L.y; a.z = a.z + L.z; a.w = a.w + 1.0f; }
+            fc += k == 0u ? p.fc_inc0 : 1u;
         }
+        accum[px] = a;
     }
 }
 

@@ -122,3 +122,34 @@ def test_blue_noise_mode_matches_oracle(device, atrium):
     assert img.tobytes() == orc.resolve(acc).tobytes()
     plain, _, _ = render_desc(device, desc, w, h, bounces, frames)
     assert plain.tobytes() != img.tobytes()
+
+
+def test_raytrace_n_equals_n_sequential_calls(device, atrium):
+    """lpt_renderer_raytrace_n(view, n) is bit-identical to n x { raytrace(view); accumulate = true }, from a
+    reset state and when continuing an accumulation, and leaves the same frame_count / seed behind."""
+    desc, _ = atrium
+    sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
+    pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    out = []
+    for batched in (False, True):
+        r = lp.Renderer(device, (200, 120))      # 120 rows: not a whole number of 8-row tiles
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (200, 120))
+        r.set_max_bounces(5)
+        r.set_vfov(T.VFOV)
+        r.reset_accumulation()                   # accumulate == false: the first call overwrites, no increment
+        if batched:
+            r.raytrace_n(view, 3)
+            r.raytrace_n(view, 2)
+        else:
+            for _ in range(5):
+                r.raytrace(view)
+                r.accumulate = True              # app.rs:318
+        out.append((r.read_radiance(), r.frame_state(), r.ray_counts().closest, r.accumulate))
+        r.close()
+    pr.close()
+    sg.close()
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    assert out[0][1:] == out[1][1:]
+    assert np.all(out[0][0][..., 3] == 1.0)
