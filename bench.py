@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, reduce) even with one rank")
     ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
@@ -82,7 +83,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dev = lp.Device(local_rank)
@@ -103,7 +107,7 @@ def main():
     ext = torch.cuda.ExternalStream(dev.stream(), device=torch.device("cuda", local_rank))
     ptr, nbytes = r.radiance_device_ptr()
     accum = torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank))
-    frame = torch.empty_like(accum) if world > 1 else None
+    frame = torch.empty_like(accum) if use_dist else None
 
     def step():
         r.reset_accumulation()
@@ -113,7 +117,7 @@ def main():
         else:
             for _ in range(SPP):
                 r.raytrace(view)
-        if world > 1:
+        if use_dist:
             # radiance reduce over xGMI: ordered after the renderer's stream, which the next
             # frame's kernels in turn wait on (torch issues the RCCL op relative to `ext`)
             with torch.cuda.stream(ext):
@@ -121,7 +125,7 @@ def main():
                 dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -142,7 +146,7 @@ def main():
 
     tl = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([counts.closest, counts.shadow, counts.shaded], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tl.item())
@@ -209,7 +213,7 @@ def main():
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     r.close()
