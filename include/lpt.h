@@ -293,6 +293,11 @@ int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t wi
 int lpt_renderer_use_noise(lpt_renderer *r, int flag);
 /* replaces: Renderer::set_blit_mode (renderer.rs:675-681) */
 int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode);
+/* replaces: the ASVGF ping-pong targets the debug BlitModes expose (renderer.rs:557-589,
+ * render/asvgf.rs:9-152): current G-buffer (w*h*4 u32: prim id, depth bits, oct normal, RGBA8 albedo),
+ * motion (w*h*2 f32, uv units), temporally accumulated radiance+variance (w*h*4 f32), history (w*h u32).
+ * Any pointer may be NULL.  Blocking.  Parity surface for the denoiser path. */
+int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion, float *radiance, uint32_t *history);
 /* replaces: Renderer::blit(&Device,&mut encoder,&TextureView) (renderer.rs:551-607):
  * tonemapped sRGB RGBA8 of the current target into caller memory. */
 int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "lpt_renderer_blit_rgba8": (_i, [_vp, _vp, _sz]),
     "lpt_renderer_read_pixels": (_i, [_vp, _vp]),
     "lpt_renderer_read_radiance": (_i, [_vp, _vp]),
+    "lpt_renderer_read_denoiser": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "lpt_renderer_get_timings": (_i, [_vp, _vp, C.POINTER(_i)]),
     "lpt_renderer_enable_timings": (_i, [_vp, _i]),
     "lpt_renderer_set_max_bounces": (_i, [_vp, _u32]),

@@ -331,6 +331,14 @@ class Renderer:
         _check(A.lib().lpt_renderer_read_radiance(self._h, A.ptr(out)))
         return out
 
+    def read_denoiser(self):
+        """current G-buffer / motion / accumulated radiance+variance / history of the ASVGF path"""
+        w, h = self.get_size()
+        g, m = np.zeros((h, w, 4), np.uint32), np.zeros((h, w, 2), np.float32)
+        rad, hist = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.uint32)
+        _check(A.lib().lpt_renderer_read_denoiser(self._h, A.ptr(g), A.ptr(m), A.ptr(rad), A.ptr(hist)))
+        return g, m, rad, hist
+
     def frame_state(self):
         fc, seed = C.c_uint32(), C.c_uint32()
         _check(A.lib().lpt_renderer_get_frame_state(self._h, C.byref(fc), C.byref(seed)))

@@ -44,8 +44,8 @@ struct lpt_probe {
     void *rgbe = nullptr;
 };
 
-enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_COUNT };
-static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation"};
+enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_COUNT };
+static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf"};
 
 struct lpt_renderer {
     lpt_device *dev = nullptr;
@@ -79,6 +79,16 @@ struct lpt_renderer {
     void *default_probe = nullptr;
     void *noise = nullptr;
     uint32_t noise_w = 0, noise_h = 0;
+    // denoiser path (reference render/asvgf.rs ScreenResources :9-152): 2x ping-pong {radiance, gbuffer, moments,
+    // history} + motion + radiance_temp; allocated on first use of a denoising BlitMode
+    uint4 *den_gbuf[2]{};
+    float4 *den_rad[2]{};
+    float2 *den_mom[2]{};
+    uint32_t *den_hist[2]{};
+    float2 *den_motion = nullptr;
+    float4 *den_temp = nullptr;
+    int den_cur = 1;              // current_frame_back starts true (asvgf.rs:233); start() flips it
+    CamBasis prev_cam{};          // prev_model_to_screen (renderer.rs:201,319,542-546), identity at start
     // per-stage timing: a ring of event sets (one per raytrace() call) harvested lazily, so
     // timing a run never stalls the host on the frame it has just enqueued
     static constexpr int kRing = 8;
@@ -319,7 +329,42 @@ int lpt_trace_occluded(lpt_device *dev, const lpt_scene_gpu *sg, const float *or
 }
 
 // ============================================================================ Renderer
+static void free_denoiser(lpt_renderer *r) {
+    for (int k = 0; k < 2; ++k) {
+        if (r->den_gbuf[k]) hipFree(r->den_gbuf[k]);
+        if (r->den_rad[k]) hipFree(r->den_rad[k]);
+        if (r->den_mom[k]) hipFree(r->den_mom[k]);
+        if (r->den_hist[k]) hipFree(r->den_hist[k]);
+        r->den_gbuf[k] = nullptr; r->den_rad[k] = nullptr; r->den_mom[k] = nullptr; r->den_hist[k] = nullptr;
+    }
+    if (r->den_motion) hipFree(r->den_motion);
+    if (r->den_temp) hipFree(r->den_temp);
+    r->den_motion = nullptr; r->den_temp = nullptr;
+    r->den_cur = 1;
+}
+
+static int ensure_denoiser(lpt_renderer *r) {
+    if (r->den_temp) return LPT_OK;
+    const size_t n = (size_t)r->w * r->h;
+    hipStream_t s = r->dev->stream;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipMalloc(&r->den_gbuf[k], sizeof(uint4) * n));
+        HIP_TRY(hipMalloc(&r->den_rad[k], sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&r->den_mom[k], sizeof(float2) * n));
+        HIP_TRY(hipMalloc(&r->den_hist[k], sizeof(uint32_t) * n));
+        HIP_TRY(hipMemsetAsync(r->den_gbuf[k], 0, sizeof(uint4) * n, s));
+        HIP_TRY(hipMemsetAsync(r->den_rad[k], 0, sizeof(float4) * n, s));
+        HIP_TRY(hipMemsetAsync(r->den_mom[k], 0, sizeof(float2) * n, s));
+        HIP_TRY(hipMemsetAsync(r->den_hist[k], 0, sizeof(uint32_t) * n, s));  // history 0 = nothing to reproject
+    }
+    HIP_TRY(hipMalloc(&r->den_motion, sizeof(float2) * n));
+    HIP_TRY(hipMalloc(&r->den_temp, sizeof(float4) * n));
+    HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * n, s));
+    return LPT_OK;
+}
+
 static void free_frame_buffers(lpt_renderer *r) {
+    free_denoiser(r);  // Renderer::resize re-creates the ASVGF resources (renderer.rs:347-355)
     void *ptrs[] = {r->q[0].o, r->q[0].d, r->q[0].T, r->q[1].o, r->q[1].d, r->q[1].T, r->sq.o, r->sq.d, r->sq.c, r->hits, r->Lsum, r->accum, r->scratch};
     for (void *p : ptrs) if (p) hipFree(p);
     r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
@@ -380,6 +425,8 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     r->dev = dev;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
+    r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
+    r->prev_cam.fwd = mk3(0.f, 0.f, 1.f); r->prev_cam.ax = r->prev_cam.ay = 1.0f;   // Mat4::IDENTITY (renderer.rs:319)
     r->req_w = width; r->req_h = height;
     // get_downsampled_size (renderer.rs:18-22)
     r->w = (uint32_t)((float)width * r->downsample);
@@ -574,6 +621,15 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) { return lpt_re
 int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_samples) {
     if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
     if (n_samples == 0u || n_samples > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace_n: n must be in [1,64]");
+    if (r->mode != LPT_BLIT_PATHTRACE && n_samples > 1u) {
+        // the denoiser consumes one sample per frame (temporal pass per raytrace): no batching
+        for (uint32_t k = 0; k < n_samples; ++k) {
+            int st = lpt_renderer_raytrace_n(r, view, 1u);
+            if (st != LPT_OK) return st;
+            r->accumulate = true;
+        }
+        return LPT_OK;
+    }
     if (n_samples & 1u) r->frame_back = !r->frame_back;   // renderer.rs:401, once per emulated call
     if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
     if (!r->w || !r->h) return LPT_OK;
@@ -605,6 +661,18 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         if (st != LPT_OK) return st;
     }
     const uint32_t n_rays = p.n_slots * n_samples;
+    const bool denoise = r->mode != LPT_BLIT_PATHTRACE;
+    GBufArgs gb{};
+    if (denoise) {
+        if (r->world != 1u) return fail(LPT_ERR_INVALID_ARG, "the denoising BlitModes need the whole frame on one GPU (world_size 1)");
+        int st = ensure_denoiser(r);
+        if (st != LPT_OK) return st;
+        r->den_cur = 1 - r->den_cur;         // asvgf.start() (renderer.rs:467)
+        gb.gbuf = r->den_gbuf[r->den_cur];
+        gb.motion = r->den_motion;
+        gb.cur.origin = p.origin; gb.cur.right = p.right; gb.cur.up = p.up; gb.cur.fwd = p.fwd; gb.cur.ax = p.ax; gb.cur.ay = p.ay;
+        gb.prev = r->prev_cam;
+    }
 
     DProbe probe = r->probe ? r->probe->d : DProbe{(const uint8_t *)r->default_probe, 1u, 1u};
     DNoise nz{(const uint8_t *)r->noise, r->noise_w, r->noise_h, (r->use_noise && r->noise) ? 1u : 0u};
@@ -640,26 +708,52 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
             else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
             stage_end(r);
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
-            hipLaunchKernelGGL(k_shade, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed);
+            if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
+                hipLaunchKernelGGL(k_shade<true>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
+            else
+                hipLaunchKernelGGL(k_shade<false>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
             stage_end(r);
             stage_begin(r, ST_SHADOW);
             if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
             else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
             stage_end(r);
         }
-        if (r->mode == LPT_BLIT_PATHTRACE || true) {
-            // AccumulationPass (:523-538).  The denoiser modes are not built yet; every mode accumulates.
+        if (r->mode == LPT_BLIT_PATHTRACE) {
+            // AccumulationPass (:523-538)
             stage_begin(r, ST_ACCUM);
             hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->accum);
             stage_end(r);
-        }
+        } else if (r->mode == LPT_BLIT_DENOISED || r->mode == LPT_BLIT_TEMPORAL) {
+            // asvgf.render (:513-518, asvgf.rs:250-291) / asvgf.temporal_pass (:519-522)
+            stage_begin(r, ST_ASVGF);
+            const int cur = r->den_cur, prv = 1 - r->den_cur;
+            const uint32_t npx = r->w * r->h;
+            const uint32_t px_blocks = div_up(npx, kBlock);
+            hipLaunchKernelGGL(k_temporal, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->den_gbuf[cur], r->den_gbuf[prv], r->den_motion,
+                               r->den_rad[prv], r->den_mom[prv], r->den_hist[prv], r->den_rad[cur], r->den_mom[cur], r->den_hist[cur]);
+            const float4 *result = r->den_rad[cur];
+            if (r->mode == LPT_BLIT_DENOISED) {
+                HIP_TRY(hipMemcpyAsync(r->den_temp, r->den_rad[cur], sizeof(float4) * npx, hipMemcpyDeviceToDevice, s));  // copy_texture_to_texture
+                // even number of a-trous calls: main <-> radiance_temp, result ends in radiance_temp (asvgf.rs:286-287)
+                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 1);
+                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 2);
+                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 4);
+                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 8);
+                result = r->den_temp;
+            }
+            hipLaunchKernelGGL(k_composite, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], result, r->accum, npx);
+            stage_end(r);
+        }  // GBuffer / MotionVector: the primary pass has written the debug targets; nothing else runs (:539)
         hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, s, r->ctr, r->totals, nb);
         HIP_TRY(hipGetLastError());
     }
     // bookkeeping of n emulated calls: { raytrace(); accumulate = true (app.rs:318); } x n
     r->seed += nb * n_samples;                   // seed += 1 per intersect stage, never reset
-    if (r->accumulate) r->frame_count += 1u;     // :535-537 for the first call
-    r->frame_count += n_samples - 1u;            // later calls run with accumulate == true
+    if (r->mode == LPT_BLIT_PATHTRACE) {         // frame_count only moves in the Pahtrace arm (:523-538)
+        if (r->accumulate) r->frame_count += 1u; // :535-537 for the first call
+        r->frame_count += n_samples - 1u;        // later calls run with accumulate == true
+    }
+    if (denoise) r->prev_cam = gb.cur;           // prev_model_to_screen = P * V^-1 (:542-546)
     if (n_samples > 1u) r->accumulate = true;
     return LPT_OK;
 }
@@ -695,7 +789,14 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);
     const uint32_t n = r->w * r->h;
-    if (e == hipSuccess) { hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, (uchar4 *)r->scratch, n); e = hipGetLastError(); }
+    if (e == hipSuccess) {
+        if ((r->mode == LPT_BLIT_GBUFFER || r->mode == LPT_BLIT_MOTION) && r->den_temp)  // debug views (renderer.rs:574-586)
+            hipLaunchKernelGGL(k_debug_view, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->den_gbuf[r->den_cur], r->den_motion,
+                               (uchar4 *)r->scratch, (int)r->w, (int)r->h, r->mode);
+        else
+            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, (uchar4 *)r->scratch, n);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->dev->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->dev->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
@@ -704,7 +805,25 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
 
 int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst) {
     if (!r || !dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_pixels: null");
-    return lpt_renderer_blit_rgba8(r, dst, (size_t)r->w * 4);
+    const int mode = r->mode;  // read_pixels always reads `main` (renderer.rs:769), whatever the blit mode
+    if (mode == LPT_BLIT_GBUFFER || mode == LPT_BLIT_MOTION) r->mode = LPT_BLIT_PATHTRACE;
+    const int st = lpt_renderer_blit_rgba8(r, dst, (size_t)r->w * 4);
+    r->mode = mode;
+    return st;
+}
+
+int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion, float *radiance, uint32_t *history) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_denoiser: null");
+    if (!r->den_temp) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no denoising frame has been traced");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    const size_t n = (size_t)r->w * r->h;
+    const int c = r->den_cur;
+    if (gbuffer) HIP_TRY(hipMemcpy(gbuffer, r->den_gbuf[c], sizeof(uint4) * n, hipMemcpyDeviceToHost));
+    if (motion) HIP_TRY(hipMemcpy(motion, r->den_motion, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    if (radiance) HIP_TRY(hipMemcpy(radiance, r->den_rad[c], sizeof(float4) * n, hipMemcpyDeviceToHost));
+    if (history) HIP_TRY(hipMemcpy(history, r->den_hist[c], sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return LPT_OK;
 }
 
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {

@@ -538,10 +538,60 @@ __device__ __forceinline__ f3 env_lookup(const DProbe &pr, f3 d) {
     return r;
 }
 
+// ------------------------------------------------------------------ SPEC §15 helpers (denoiser path)
+__device__ __forceinline__ uint32_t oct_encode(f3 n) {
+    float l1 = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    float px = 0.0f, py = 0.0f;
+    if (l1 > 0.0f) { px = n.x / l1; py = n.y / l1; }
+    if (n.z < 0.0f) {
+        float tx = (1.0f - fabsf(py)) * (px >= 0.0f ? 1.0f : -1.0f);
+        float ty = (1.0f - fabsf(px)) * (py >= 0.0f ? 1.0f : -1.0f);
+        px = tx; py = ty;
+    }
+    uint32_t ux = (uint32_t)(clampf(px * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
+    uint32_t uy = (uint32_t)(clampf(py * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
+    return ux | (uy << 16);
+}
+__device__ __forceinline__ f3 oct_decode(uint32_t p) {
+    float fx = (float)(p & 0xFFFFu) * 3.0518043793392844e-05f - 1.0f;
+    float fy = (float)(p >> 16) * 3.0518043793392844e-05f - 1.0f;
+    float fz = (1.0f - fabsf(fx)) - fabsf(fy);
+    if (fz < 0.0f) {
+        float tx = (1.0f - fabsf(fy)) * (fx >= 0.0f ? 1.0f : -1.0f);
+        float ty = (1.0f - fabsf(fx)) * (fy >= 0.0f ? 1.0f : -1.0f);
+        fx = tx; fy = ty;
+    }
+    return normalize(mk3(fx, fy, fz));
+}
+__device__ __forceinline__ uint32_t pack_albedo(f3 a) {
+    uint32_t r = (uint32_t)(clampf(a.x, 0.0f, 1.0f) * 255.0f + 0.5f), g = (uint32_t)(clampf(a.y, 0.0f, 1.0f) * 255.0f + 0.5f);
+    uint32_t b = (uint32_t)(clampf(a.z, 0.0f, 1.0f) * 255.0f + 0.5f);
+    return r | (g << 8) | (b << 16) | 0xFF000000u;
+}
+__device__ __forceinline__ f3 demod_albedo(uint32_t p) {
+    return mk3(max2((float)(p & 0xFFu) * 0.003921568859368563f, 0.05f), max2((float)((p >> 8) & 0xFFu) * 0.003921568859368563f, 0.05f),
+               max2((float)((p >> 16) & 0xFFu) * 0.003921568859368563f, 0.05f));
+}
+struct CamBasis { f3 origin, right, up, fwd; float ax, ay; };  // world -> screen, the build's `model_to_screen`
+__device__ __forceinline__ bool project(const CamBasis &c, f3 P, float &u, float &v) {
+    f3 w = P - c.origin;
+    float cz = dot(w, c.fwd);
+    if (!(cz > 1.0e-6f)) return false;
+    float cx = dot(w, c.right), cy = dot(w, c.up);
+    u = 0.5f + 0.5f * (cx / (cz * c.ax));
+    v = 0.5f - 0.5f * (cy / (cz * c.ay));
+    return true;
+}
+__device__ __forceinline__ float pow128(float x) { x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; return x; }
+// what the primary pass writes besides the path state (reference PrimaryRayPass: gbuffer Rgba32Uint + motion Rg32F,
+// asvgf.rs:39-70,104-117; prev_model_to_screen push constant, renderer.rs:472-479)
+struct GBufArgs { uint4 *gbuf; float2 *motion; CamBasis cur, prev; };
+
 // ------------------------------------------------------------------ shading (SPEC §12)
+template <bool GBUF>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
-                                                  uint32_t seed_base) {
+                                                  uint32_t seed_base, GBufArgs gb) {
     __shared__ uint32_t lds[8];
     const uint32_t count = ctr->qcount[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -559,6 +609,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
             const f3 T = mk3(T4.x, T4.y, T4.z);
             const float pdf_prev = d4.w;
             const uint32_t prim = __float_as_uint(h4.w);
+            // primary-hit record for the G-buffer (SPEC §15.1); defaults cover miss / emitter / degenerate
+            f3 g_n = neg(d), g_alb = mk3(1.0f, 1.0f, 1.0f);
+            f3 g_P = mk3(fmaf(d.x, h4.x, o4.x), fmaf(d.y, h4.x, o4.y), fmaf(d.z, h4.x, o4.z));
             if (prim == 0xFFFFFFFFu) {
                 const f3 e = env_lookup(probe, d);
                 float4 L = Lsum[slot];
@@ -568,6 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                 const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + (prim & ~LPT_LIGHT_BIT));
                 const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
                 const float Le = lo4.w;
+                g_n = mk3(n4.x, n4.y, n4.z);
                 float w = 1.0f;
                 if (pdf_prev >= 0.0f) {
                     float cl = -dot(mk3(n4.x, n4.y, n4.z), d);
@@ -614,6 +668,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                         const float4 tex = texture_lookup(sc, mtex, tu, tvv, false);
                         rough *= tex.y; metal *= tex.z;
                     }
+                    g_n = Ns; g_P = P;
+                    g_alb = mk3(clampf(base.x, 0.0f, 1.0f), clampf(base.y, 0.0f, 1.0f), clampf(base.z, 0.0f, 1.0f));
                     const Surface sf = make_surface(base, rough, metal);
                     const f3 V = neg(d);
                     const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
@@ -683,6 +739,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     }
                 }
             }
+            if (GBUF && bounce == 0) {
+                uint32_t gx = 0, gy = 0;
+                slot_to_pixel(p, slot % p.n_slots, gx, gy);
+                const size_t px = (size_t)gy * p.width + gx;
+                gb.gbuf[px] = make_uint4(prim, __float_as_uint(h4.x), oct_encode(g_n), pack_albedo(g_alb));
+                float mu = 0.0f, mv = 0.0f, cu, cv, pu, pv;
+                if (prim != 0xFFFFFFFFu && project(gb.cur, g_P, cu, cv) && project(gb.prev, g_P, pu, pv)) { mu = pu - cu; mv = pv - cv; }
+                gb.motion[px] = make_float2(mu, mv);
+            }
         }
         const uint32_t si = block_compact(want_shadow, &ctr->shcount[bounce], lds);
         if (want_shadow) { sq.o[si] = so4; sq.d[si] = sd4; sq.c[si] = sc4; }
@@ -713,6 +778,115 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
             fc += k == 0u ? p.fc_inc0 : 1u;
         }
         accum[px] = a;
+    }
+}
+
+// ------------------------------------------------------------------ denoiser passes (SPEC §15.2-15.4)
+// TemporalAccumulationPass (asvgf.rs:245-247): nearest reprojection + consistency test, moments, history
+__global__ __launch_bounds__(kBlock) void k_temporal(FrameParams p, const float4 *Lsum, const uint4 *g_cur, const uint4 *g_prev, const float2 *motion,
+                                                     const float4 *rad_prev, const float2 *mom_prev, const uint32_t *hist_prev,
+                                                     float4 *rad_cur, float2 *mom_cur, uint32_t *hist_cur) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int W = (int)p.width, H = (int)p.height;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(p, slot, x, y)) continue;
+        const size_t i = (size_t)y * W + x;
+        const uint4 g = g_cur[i];
+        const f3 a = demod_albedo(g.w);
+        const float4 L = Lsum[slot];
+        const f3 il = mk3(L.x / a.x, L.y / a.y, L.z / a.z);
+        const float lm = lum(il);
+        const float2 mo = motion[i];
+        const int mx = (int)floorf(((float)x + 0.5f) + mo.x * (float)W);
+        const int my = (int)floorf(((float)y + 0.5f) + mo.y * (float)H);
+        uint32_t hn = 1u;
+        f3 col = il;
+        float m1 = lm, m2 = lm * lm;
+        if (mx >= 0 && my >= 0 && mx < W && my < H) {
+            const size_t j = (size_t)my * W + mx;
+            const uint4 gp = g_prev[j];
+            const uint32_t hp = hist_prev[j];
+            const float zc = __uint_as_float(g.y), zp = __uint_as_float(gp.y);
+            const bool ok = hp > 0u && gp.x == g.x && dot(oct_decode(g.z), oct_decode(gp.z)) >= 0.9f && fabsf(zc - zp) <= 0.1f * max2(zc, zp);
+            if (ok) {
+                hn = hp + 1u;
+                if (hn > 64u) hn = 64u;
+                const float al = 1.0f / (float)hn;
+                const float4 pc = rad_prev[j];
+                const float2 pm = mom_prev[j];
+                col = mk3(pc.x + (il.x - pc.x) * al, pc.y + (il.y - pc.y) * al, pc.z + (il.z - pc.z) * al);
+                m1 = pm.x + (lm - pm.x) * al;
+                m2 = pm.y + (lm * lm - pm.y) * al;
+            }
+        }
+        float var = max2(m2 - m1 * m1, 0.0f);
+        if (hn < 4u) var = var + (m1 * m1) * ((float)(4u - hn) * 0.25f);
+        rad_cur[i] = make_float4(col.x, col.y, col.z, var);
+        mom_cur[i] = make_float2(m1, m2);
+        hist_cur[i] = hn;
+    }
+}
+
+// ATrousPass (asvgf.rs:278-287): 5x5 B3-spline taps `step` pixels apart, edge-stopping on normal / depth / luminance
+__global__ __launch_bounds__(kBlock) void k_atrous(const uint4 *gb, const float4 *in, float4 *out, int W, int H, int step) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)(W * H)) return;
+    const int y = (int)(idx / (uint32_t)W), x = (int)(idx - (uint32_t)y * (uint32_t)W);
+    const float kw[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    const uint4 g = gb[idx];
+    const float4 c = in[idx];
+    if (g.x == 0xFFFFFFFFu) { out[idx] = c; return; }
+    const f3 nc = oct_decode(g.z);
+    const float zc = __uint_as_float(g.y);
+    const float lc = lum(mk3(c.x, c.y, c.z));
+    const float sigma_l = 4.0f * sqrtf(max2(c.w, 0.0f)) + 1.0e-4f;
+    const float sigma_z = 0.02f * zc + 1.0e-6f;
+    const float wc = kw[2] * kw[2];
+    float sr = c.x * wc, sg = c.y * wc, sb = c.z * wc, sv = c.w * (wc * wc), sw = wc;
+    for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            const int qx = x + dx * step, qy = y + dy * step;
+            if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
+            const size_t j = (size_t)qy * W + qx;
+            const uint4 gq = gb[j];
+            if (gq.x == 0xFFFFFFFFu) continue;
+            const float4 q = in[j];
+            const float zq = __uint_as_float(gq.y);
+            const float wn = pow128(max2(dot(nc, oct_decode(gq.z)), 0.0f));
+            const float rz = fabsf(zc - zq) / sigma_z;
+            const float wz = 1.0f / (1.0f + rz * rz);
+            const float rl = fabsf(lc - lum(mk3(q.x, q.y, q.z))) / sigma_l;
+            const float wl = 1.0f / (1.0f + rl * rl);
+            const float w = ((kw[dx + 2] * kw[dy + 2]) * wn) * (wz * wl);
+            sr += q.x * w; sg += q.y * w; sb += q.z * w; sv += q.w * (w * w); sw += w;
+        }
+    const float inv = 1.0f / sw;
+    out[idx] = make_float4(sr * inv, sg * inv, sb * inv, sv * (inv * inv));
+}
+
+// CompositingPass (asvgf.rs:288-290): re-modulate with the primary albedo into the main target
+__global__ __launch_bounds__(kBlock) void k_composite(const uint4 *gb, const float4 *in, float4 *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 a = demod_albedo(gb[i].w);
+    const float4 c = in[i];
+    out[i] = make_float4(c.x * a.x, c.y * a.y, c.z * a.z, 1.0f);
+}
+
+// debug views of BlitMode::GBuffer / MotionVector (renderer.rs:574-586)
+__global__ __launch_bounds__(kBlock) void k_debug_view(const uint4 *gb, const float2 *motion, uchar4 *out, int W, int H, int mode) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)(W * H)) return;
+    if (mode == 3) {
+        const f3 n = oct_decode(gb[i].z);
+        out[i] = make_uchar4((uint8_t)((n.x * 0.5f + 0.5f) * 255.0f + 0.5f), (uint8_t)((n.y * 0.5f + 0.5f) * 255.0f + 0.5f),
+                             (uint8_t)((n.z * 0.5f + 0.5f) * 255.0f + 0.5f), 255);
+    } else {
+        const float2 m = motion[i];
+        out[i] = make_uchar4((uint8_t)(clampf(fabsf(m.x) * (float)W * 0.125f, 0.0f, 1.0f) * 255.0f + 0.5f),
+                             (uint8_t)(clampf(fabsf(m.y) * (float)H * 0.125f, 0.0f, 1.0f) * 255.0f + 0.5f), 0, 255);
     }
 }
 

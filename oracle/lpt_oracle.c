@@ -619,8 +619,11 @@ void orc_raygen(const orc_render_params *p, uint32_t x, uint32_t y, float origin
 }
 
 /* ------------------------------------------------------------------ SPEC §12 one sample of one pixel */
+/* primary-hit record for the G-buffer (SPEC §15.1) */
+typedef struct { uint32_t prim; float depth; v3 n; float albedo[3]; v3 P; int has_P; } primary_t;
+
 static void trace_sample(const orc_scene *s, const orc_render_params *p, const cam_t *cam, uint32_t x, uint32_t y,
-                         uint32_t seed_counter, float Lout[3], orc_counters *c) {
+                         uint32_t seed_counter, float Lout[3], orc_counters *c, primary_t *pr) {
     uint32_t pixel = y * p->width + x;
     v3 o, d;
     raygen(s, p, cam, x, y, seed_counter, &o, &d);
@@ -633,6 +636,16 @@ static void trace_sample(const orc_scene *s, const orc_render_params *p, const c
         orc_hit h;
         closest_one(s, oo, dd, &h, (int)p->brute_force, c);
         if (c) c->closest++;
+        if (pr && b == 0u) { /* defaults: miss / emitter / degenerate */
+            pr->prim = h.prim; pr->depth = h.t; pr->n = neg3(d);
+            pr->albedo[0] = pr->albedo[1] = pr->albedo[2] = 1.0f;
+            pr->has_P = h.prim != ORC_INVALID;
+            pr->P = V3(fmaf(d.x, h.t, o.x), fmaf(d.y, h.t, o.y), fmaf(d.z, h.t, o.z));
+            if ((h.prim & ORC_LIGHT_BIT) && h.prim != ORC_INVALID) {
+                const orc_light *Lg = &s->lights[h.prim & ~ORC_LIGHT_BIT];
+                pr->n = V3(Lg->normal[0], Lg->normal[1], Lg->normal[2]);
+            }
+        }
         if (h.prim == ORC_INVALID) { /* miss: environment */
             float e[3];
             orc_env_lookup(s, dd, e);
@@ -689,6 +702,10 @@ static void trace_sample(const orc_scene *s, const orc_render_params *p, const c
             float tex[4];
             orc_texture_lookup(s, M->mra_texture, tu, tv, 0, tex);
             rough *= tex[1]; metal *= tex[2];
+        }
+        if (pr && b == 0u) {
+            pr->n = Ns; pr->P = P;
+            pr->albedo[0] = clampf(base[0], 0.0f, 1.0f); pr->albedo[1] = clampf(base[1], 0.0f, 1.0f); pr->albedo[2] = clampf(base[2], 0.0f, 1.0f);
         }
         surf_t sf = make_surface(base, rough, metal);
         v3 Vv = neg3(d);
@@ -785,7 +802,7 @@ static void *worker(void *arg) {
             uint32_t frame_count = 1; /* reset_accumulation(): renderer.rs:610 */
             for (uint32_t f = 0; f < p->frames; ++f) {
                 float L[3];
-                trace_sample(j->s, p, &j->cam, x, y, seed, L, j->counters ? &local : NULL);
+                trace_sample(j->s, p, &j->cam, x, y, seed, L, j->counters ? &local : NULL, NULL);
                 seed += p->max_bounces;
                 /* AccumulationPass (renderer.rs:525-537), stored as (sum, count) */
                 if (frame_count == 1u) { acc[0] = L[0]; acc[1] = L[1]; acc[2] = L[2]; acc[3] = 1.0f; }
@@ -843,4 +860,197 @@ void orc_tonemap(const float *accum, uint32_t n, uint8_t *rgba8) {
         for (int ch = 0; ch < 3; ++ch) rgba8[4 * (size_t)i + ch] = encode_srgb8(cnt > 0.0f ? accum[4 * (size_t)i + ch] / cnt : 0.0f);
         rgba8[4 * (size_t)i + 3] = 255;
     }
+}
+
+/* ================================================================== SPEC §15: denoiser path
+ * Restates the pass sequence of reference crates/lib/src/render/asvgf.rs:250-291 (temporal ->
+ * copy -> a-trous x even count -> composite; ping-pong resources :9-152) and of
+ * Renderer::raytrace in BlitMode::DenoisedPathrace / Temporal (renderer.rs:466-481,512-522,542-546).
+ * The per-pixel filters are specified in SPEC.md §15 (the reference's live in albedo_rtx). */
+struct orc_denoiser {
+    uint32_t w, h; int cur;
+    uint32_t *gbuf[2]; float *rad[2]; float *mom[2]; uint32_t *hist[2];
+    float *motion, *temp, *lsum;
+    cam_t prev_cam;
+};
+
+orc_denoiser *orc_denoiser_create(uint32_t w, uint32_t h) {
+    orc_denoiser *d = (orc_denoiser *)calloc(1, sizeof *d);
+    size_t n = (size_t)w * h;
+    d->w = w; d->h = h; d->cur = 1; /* current_frame_back starts true (asvgf.rs:233), start() flips it */
+    for (int k = 0; k < 2; ++k) {
+        d->gbuf[k] = (uint32_t *)calloc(n * 4, 4); d->rad[k] = (float *)calloc(n * 4, 4);
+        d->mom[k] = (float *)calloc(n * 2, 4); d->hist[k] = (uint32_t *)calloc(n, 4);
+    }
+    d->motion = (float *)calloc(n * 2, 4); d->temp = (float *)calloc(n * 4, 4); d->lsum = (float *)calloc(n * 4, 4);
+    /* prev_model_to_screen starts as the identity (renderer.rs:319) */
+    d->prev_cam.origin = V3(0, 0, 0); d->prev_cam.right = V3(1, 0, 0); d->prev_cam.up = V3(0, 1, 0); d->prev_cam.fwd = V3(0, 0, 1);
+    d->prev_cam.ax = d->prev_cam.ay = 1.0f;
+    return d;
+}
+void orc_denoiser_destroy(orc_denoiser *d) {
+    if (!d) return;
+    for (int k = 0; k < 2; ++k) { free(d->gbuf[k]); free(d->rad[k]); free(d->mom[k]); free(d->hist[k]); }
+    free(d->motion); free(d->temp); free(d->lsum); free(d);
+}
+void orc_denoiser_read(const orc_denoiser *d, uint32_t *gbuf_cur, float *motion, float *rad_cur, uint32_t *hist_cur) {
+    size_t n = (size_t)d->w * d->h;
+    if (gbuf_cur) memcpy(gbuf_cur, d->gbuf[d->cur], n * 16);
+    if (motion) memcpy(motion, d->motion, n * 8);
+    if (rad_cur) memcpy(rad_cur, d->rad[d->cur], n * 16);
+    if (hist_cur) memcpy(hist_cur, d->hist[d->cur], n * 4);
+}
+
+static inline uint32_t oct_encode(v3 n) {
+    float l1 = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    float px = 0.0f, py = 0.0f;
+    if (l1 > 0.0f) { px = n.x / l1; py = n.y / l1; }
+    if (n.z < 0.0f) {
+        float tx = (1.0f - fabsf(py)) * (px >= 0.0f ? 1.0f : -1.0f);
+        float ty = (1.0f - fabsf(px)) * (py >= 0.0f ? 1.0f : -1.0f);
+        px = tx; py = ty;
+    }
+    uint32_t ux = (uint32_t)(clampf(px * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
+    uint32_t uy = (uint32_t)(clampf(py * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
+    return ux | (uy << 16);
+}
+static inline v3 oct_decode(uint32_t p) {
+    float fx = (float)(p & 0xFFFFu) * 3.0518043793392844e-05f - 1.0f;
+    float fy = (float)(p >> 16) * 3.0518043793392844e-05f - 1.0f;
+    float fz = (1.0f - fabsf(fx)) - fabsf(fy);
+    if (fz < 0.0f) {
+        float tx = (1.0f - fabsf(fy)) * (fx >= 0.0f ? 1.0f : -1.0f);
+        float ty = (1.0f - fabsf(fx)) * (fy >= 0.0f ? 1.0f : -1.0f);
+        fx = tx; fy = ty;
+    }
+    return normalize3(V3(fx, fy, fz));
+}
+static inline uint32_t pack_albedo(const float a[3]) {
+    uint32_t r = (uint32_t)(clampf(a[0], 0.0f, 1.0f) * 255.0f + 0.5f), g = (uint32_t)(clampf(a[1], 0.0f, 1.0f) * 255.0f + 0.5f);
+    uint32_t b = (uint32_t)(clampf(a[2], 0.0f, 1.0f) * 255.0f + 0.5f);
+    return r | (g << 8) | (b << 16) | 0xFF000000u;
+}
+static inline v3 demod_albedo(uint32_t p) {
+    return V3(fmax2((float)(p & 0xFFu) * 0.003921568859368563f, 0.05f), fmax2((float)((p >> 8) & 0xFFu) * 0.003921568859368563f, 0.05f),
+              fmax2((float)((p >> 16) & 0xFFu) * 0.003921568859368563f, 0.05f));
+}
+static inline int project(const cam_t *c, v3 P, float *u, float *v) {
+    v3 w = sub3(P, c->origin);
+    float cz = dot3(w, c->fwd);
+    if (!(cz > 1.0e-6f)) return 0;
+    float cx = dot3(w, c->right), cy = dot3(w, c->up);
+    *u = 0.5f + 0.5f * (cx / (cz * c->ax));
+    *v = 0.5f - 0.5f * (cy / (cz * c->ay));
+    return 1;
+}
+static inline float pow128(float x) { x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; x = x * x; return x; }
+
+static void atrous_pass(const orc_denoiser *d, const uint32_t *gb, const float *in, float *out, int step) {
+    static const float kw[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    const int W = (int)d->w, H = (int)d->h;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)y * W + x;
+            const uint32_t *g = gb + 4 * i;
+            const float *c = in + 4 * i;
+            if (g[0] == ORC_INVALID) { out[4 * i] = c[0]; out[4 * i + 1] = c[1]; out[4 * i + 2] = c[2]; out[4 * i + 3] = c[3]; continue; }
+            v3 nc = oct_decode(g[2]);
+            float zc; memcpy(&zc, &g[1], 4);
+            float lc = lum3(V3(c[0], c[1], c[2]));
+            float sigma_l = 4.0f * sqrtf(fmax2(c[3], 0.0f)) + 1.0e-4f;
+            float sigma_z = 0.02f * zc + 1.0e-6f;
+            float wc = kw[2] * kw[2];
+            float sr = c[0] * wc, sg = c[1] * wc, sb = c[2] * wc, sv = c[3] * (wc * wc), sw = wc;
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    int qx = x + dx * step, qy = y + dy * step;
+                    if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
+                    size_t j = (size_t)qy * W + qx;
+                    const uint32_t *gq = gb + 4 * j;
+                    if (gq[0] == ORC_INVALID) continue;
+                    const float *q = in + 4 * j;
+                    float zq; memcpy(&zq, &gq[1], 4);
+                    float wn = pow128(fmax2(dot3(nc, oct_decode(gq[2])), 0.0f));
+                    float rz = fabsf(zc - zq) / sigma_z;
+                    float wz = 1.0f / (1.0f + rz * rz);
+                    float rl = fabsf(lc - lum3(V3(q[0], q[1], q[2]))) / sigma_l;
+                    float wl = 1.0f / (1.0f + rl * rl);
+                    float w = ((kw[dx + 2] * kw[dy + 2]) * wn) * (wz * wl);
+                    sr += q[0] * w; sg += q[1] * w; sb += q[2] * w; sv += q[3] * (w * w); sw += w;
+                }
+            float inv = 1.0f / sw;
+            out[4 * i] = sr * inv; out[4 * i + 1] = sg * inv; out[4 * i + 2] = sb * inv; out[4 * i + 3] = sv * (inv * inv);
+        }
+}
+
+/* one raytrace() call in BlitMode::DenoisedPathrace (mode 1) or Temporal (mode 2); out_main = w*h*4 floats */
+void orc_denoise_frame(orc_denoiser *d, const orc_scene *s, const orc_render_params *p, int mode, float *out_main) {
+    const int W = (int)d->w, H = (int)d->h;
+    cam_t cam = make_camera(p);
+    d->cur = 1 - d->cur; /* asvgf.start() (renderer.rs:467) */
+    const int cur = d->cur, prv = 1 - d->cur;
+    /* 1. path trace one sample per pixel; the primary pass also writes G-buffer and motion */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)y * W + x;
+            primary_t pr; memset(&pr, 0, sizeof pr);
+            trace_sample(s, p, &cam, (uint32_t)x, (uint32_t)y, p->seed_counter, d->lsum + 4 * i, NULL, &pr);
+            uint32_t *g = d->gbuf[cur] + 4 * i;
+            g[0] = pr.prim; memcpy(&g[1], &pr.depth, 4); g[2] = oct_encode(pr.n); g[3] = pack_albedo(pr.albedo);
+            float mu = 0.0f, mv = 0.0f, cu, cv, pu, pv;
+            if (pr.has_P && project(&cam, pr.P, &cu, &cv) && project(&d->prev_cam, pr.P, &pu, &pv)) { mu = pu - cu; mv = pv - cv; }
+            d->motion[2 * i] = mu; d->motion[2 * i + 1] = mv;
+        }
+    /* 2. TemporalAccumulationPass (asvgf.rs:245-247): nearest reprojection, consistency test, moments, history */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)y * W + x;
+            const uint32_t *g = d->gbuf[cur] + 4 * i;
+            v3 a = demod_albedo(g[3]);
+            const float *L = d->lsum + 4 * i;
+            v3 il = V3(L[0] / a.x, L[1] / a.y, L[2] / a.z);
+            float lm = lum3(il);
+            int mx = (int)floorf(((float)x + 0.5f) + d->motion[2 * i] * (float)W);
+            int my = (int)floorf(((float)y + 0.5f) + d->motion[2 * i + 1] * (float)H);
+            uint32_t hn = 1u;
+            v3 col = il; float m1 = lm, m2 = lm * lm;
+            if (mx >= 0 && my >= 0 && mx < W && my < H) {
+                size_t j = (size_t)my * W + mx;
+                const uint32_t *gp = d->gbuf[prv] + 4 * j;
+                uint32_t hp = d->hist[prv][j];
+                float zc, zp; memcpy(&zc, &g[1], 4); memcpy(&zp, &gp[1], 4);
+                int ok = hp > 0u && gp[0] == g[0] && dot3(oct_decode(g[2]), oct_decode(gp[2])) >= 0.9f &&
+                         fabsf(zc - zp) <= 0.1f * fmax2(zc, zp);
+                if (ok) {
+                    hn = hp + 1u; if (hn > 64u) hn = 64u;
+                    float al = 1.0f / (float)hn;
+                    const float *pc = d->rad[prv] + 4 * j; const float *pm = d->mom[prv] + 2 * j;
+                    col = V3(pc[0] + (il.x - pc[0]) * al, pc[1] + (il.y - pc[1]) * al, pc[2] + (il.z - pc[2]) * al);
+                    m1 = pm[0] + (lm - pm[0]) * al; m2 = pm[1] + (lm * lm - pm[1]) * al;
+                }
+            }
+            float var = fmax2(m2 - m1 * m1, 0.0f);
+            if (hn < 4u) var = var + (m1 * m1) * ((float)(4u - hn) * 0.25f);
+            float *rc = d->rad[cur] + 4 * i;
+            rc[0] = col.x; rc[1] = col.y; rc[2] = col.z; rc[3] = var;
+            d->mom[cur][2 * i] = m1; d->mom[cur][2 * i + 1] = m2; d->hist[cur][i] = hn;
+        }
+    /* 3. copy -> a-trous x4 (steps 1,2,4,8; main <-> temp, result in temp) -> composite (asvgf.rs:257-290) */
+    size_t n = (size_t)W * H;
+    const float *result = d->rad[cur];
+    if (mode == 1) {
+        memcpy(d->temp, d->rad[cur], n * 16);
+        atrous_pass(d, d->gbuf[cur], d->temp, out_main, 1);
+        atrous_pass(d, d->gbuf[cur], out_main, d->temp, 2);
+        atrous_pass(d, d->gbuf[cur], d->temp, out_main, 4);
+        atrous_pass(d, d->gbuf[cur], out_main, d->temp, 8);
+        result = d->temp;
+    }
+    for (size_t i = 0; i < n; ++i) { /* CompositingPass: re-modulate with the primary albedo */
+        v3 a = demod_albedo(d->gbuf[cur][4 * i + 3]);
+        out_main[4 * i] = result[4 * i] * a.x; out_main[4 * i + 1] = result[4 * i + 1] * a.y; out_main[4 * i + 2] = result[4 * i + 2] * a.z;
+        out_main[4 * i + 3] = 1.0f;
+    }
+    d->prev_cam = cam; /* prev_model_to_screen = P * V^-1 (renderer.rs:542-546) */
 }

@@ -84,6 +84,14 @@ void orc_raygen(const orc_render_params *p, uint32_t x, uint32_t y, float origin
 void orc_resolve(const float *accum, uint32_t n_pixels, float *mean_rgba);
 void orc_tonemap(const float *accum, uint32_t n_pixels, uint8_t *rgba8);
 
+/* ---- denoiser path (BlitMode::DenoisedPathrace / Temporal; SPEC §15, reference render/asvgf.rs) */
+typedef struct orc_denoiser orc_denoiser;
+orc_denoiser *orc_denoiser_create(uint32_t w, uint32_t h);
+void orc_denoiser_destroy(orc_denoiser *d);
+/* one raytrace() call: mode 1 = DenoisedPathrace, 2 = Temporal; uses p->view, p->seed_counter (frames ignored) */
+void orc_denoise_frame(orc_denoiser *d, const orc_scene *s, const orc_render_params *p, int mode, float *out_main);
+void orc_denoiser_read(const orc_denoiser *d, uint32_t *gbuf_cur, float *motion, float *rad_cur, uint32_t *hist_cur);
+
 /* ---- known-answer surfaces ------------------------------------------------- */
 uint32_t orc_pcg_hash(uint32_t v);
 /* n floats of the stream keyed by (pixel, stage_seed, tag) */

@@ -61,6 +61,11 @@ def lib():
         L.orc_render.restype = u32
         L.orc_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
         L.orc_raygen.argtypes = [C.POINTER(RenderParams), u32, u32, f32p, f32p]
+        L.orc_denoiser_create.restype = vp
+        L.orc_denoiser_create.argtypes = [u32, u32]
+        L.orc_denoiser_destroy.argtypes = [vp]
+        L.orc_denoise_frame.argtypes = [vp, vp, C.POINTER(RenderParams), C.c_int, vp]
+        L.orc_denoiser_read.argtypes = [vp, vp, vp, vp, vp]
         L.orc_resolve.argtypes = [vp, u32, vp]
         L.orc_tonemap.argtypes = [vp, u32, vp]
         L.orc_pcg_hash.restype = u32
@@ -172,6 +177,41 @@ class OracleScene:
         if want_counters:
             return accum, cnt
         return accum
+
+
+class Denoiser:
+    """BlitMode::DenoisedPathrace (mode 1) / Temporal (mode 2) frame sequence on the oracle (SPEC §15)."""
+
+    def __init__(self, scene, width, height, vfov, max_bounces, user_seed=0):
+        self.scene, self.w, self.h = scene, width, height
+        self.vfov, self.bounces, self.user_seed = vfov, max_bounces, user_seed
+        self.seed_counter = 0
+        self.h_ = lib().orc_denoiser_create(width, height)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h_", None):
+                lib().orc_denoiser_destroy(self.h_)
+                self.h_ = None
+        except Exception:
+            pass
+
+    def frame(self, view, mode=1):
+        p = RenderParams()
+        p.width, p.height = self.w, self.h
+        p.view = (C.c_float * 16)(*[float(x) for x in np.asarray(view, np.float32).reshape(16)])
+        p.vfov, p.max_bounces, p.user_seed, p.seed_counter, p.frames = self.vfov, self.bounces, self.user_seed, self.seed_counter, 1
+        p.world_size = 1
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        lib().orc_denoise_frame(self.h_, self.scene.h, C.byref(p), int(mode), _p(out))
+        self.seed_counter += self.bounces
+        return out
+
+    def read(self):
+        g, m = np.zeros((self.h, self.w, 4), np.uint32), np.zeros((self.h, self.w, 2), np.float32)
+        rad, hist = np.zeros((self.h, self.w, 4), np.float32), np.zeros((self.h, self.w), np.uint32)
+        lib().orc_denoiser_read(self.h_, _p(g), _p(m), _p(rad), _p(hist))
+        return g, m, rad, hist
 
 
 def resolve(accum):
