@@ -7,6 +7,8 @@ Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponz
   start pose.  One "step" = one such frame: reset_accumulation(); accumulate=true;
   4 x Renderer::raytrace(view) — issued as lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
   Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
+  Consecutive steps alternate between two renderers with their own HIP streams (--pipeline 2), so the tail of
+  frame k (and its collective) overlaps the head of frame k+1; every step is still one complete frame.
   N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
   N grows ("strong" scaling of one frame).
 
@@ -70,7 +72,9 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, reduce) even with one rank")
+    ap.add_argument("--pipeline", type=int, default=2, help="renderers (each with its own HIP stream) that take consecutive steps in turn")
     ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
@@ -94,22 +98,30 @@ def main():
     scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, dev)
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
-    r = lp.Renderer(dev, (WIDTH, HEIGHT))
-    r.downsample_factor = 1.0
-    r.resize(dev, sg, probe, (WIDTH, HEIGHT))
-    r.set_max_bounces(DEPTH)
-    r.set_vfov(T.VFOV)
-    if world > 1:
-        r.set_shard(rank, world, 32, 8)
-        r.set_resources(dev, sg, probe)
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
-
-    ext = torch.cuda.ExternalStream(dev.stream(), device=torch.device("cuda", local_rank))
-    ptr, nbytes = r.radiance_device_ptr()
-    accum = torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank))
-    frame = torch.empty_like(accum) if use_dist else None
+    P = max(1, args.pipeline)
+    rs, exts, accums, frames = [], [], [], []
+    for _ in range(P):
+        rr = lp.Renderer(dev, (WIDTH, HEIGHT))
+        rr.downsample_factor = 1.0
+        rr.resize(dev, sg, probe, (WIDTH, HEIGHT))
+        rr.set_max_bounces(DEPTH)
+        rr.set_vfov(T.VFOV)
+        if world > 1 or args.emulate_shard > 1:
+            rr.set_shard(rank, max(world, args.emulate_shard), 32, 8)
+            rr.set_resources(dev, sg, probe)
+        rs.append(rr)
+        exts.append(torch.cuda.ExternalStream(rr.stream(), device=torch.device("cuda", local_rank)))
+        ptr, nbytes = rr.radiance_device_ptr()
+        accums.append(torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank)))
+        frames.append(torch.empty_like(accums[-1]) if use_dist else None)
+    r = rs[0]
+    step_no = [0]
 
     def step():
+        k = step_no[0] % P
+        step_no[0] += 1
+        r = rs[k]
         r.reset_accumulation()
         r.accumulate = True
         if BATCH:
@@ -118,11 +130,11 @@ def main():
             for _ in range(SPP):
                 r.raytrace(view)
         if use_dist:
-            # radiance reduce over xGMI: ordered after the renderer's stream, which the next
-            # frame's kernels in turn wait on (torch issues the RCCL op relative to `ext`)
-            with torch.cuda.stream(ext):
-                frame.copy_(accum, non_blocking=True)
-                dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+            # radiance reduce over xGMI: ordered after this renderer's stream, which its next
+            # frame's kernels in turn wait on (torch issues the RCCL op relative to the stream)
+            with torch.cuda.stream(exts[k]):
+                frames[k].copy_(accums[k], non_blocking=True)
+                dist.reduce(frames[k], dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
         if use_dist:
@@ -132,17 +144,28 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    r.reset_ray_counts()
-    r.enable_timings(True)
+    for rr in rs:
+        rr.reset_ray_counts()
+        rr.enable_timings(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    timings = r.timings()
-    r.enable_timings(False)
-    counts = r.ray_counts()
+    timings = {}
+    closest_l = shadow_l = shaded_l = 0
+    for rr in rs:
+        for k, v in rr.timings().items():
+            t0_, n0_ = timings.get(k, (0.0, 0))
+            timings[k] = (t0_ + v[0], n0_ + v[1])
+        rr.enable_timings(False)
+        c_ = rr.ray_counts()
+        closest_l += c_.closest; shadow_l += c_.shadow; shaded_l += c_.shaded
+
+    class _C:
+        closest, shadow, shaded = closest_l, shadow_l, shaded_l
+    counts = _C
 
     tl = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     rays = torch.tensor([counts.closest, counts.shadow, counts.shaded], dtype=torch.float64, device="cuda")
@@ -156,6 +179,8 @@ def main():
     # = rays/launch * (32 B ray read + 16 B hit write + N*64 B nodes + T*48 B triangles), with N, T
     # (mean nodes visited / triangles tested per closest-hit ray) measured by the stats variant of
     # the same kernel on the same frames, outside the timed region.
+    r = rs[0]
+    step_no[0] = 0
     r.enable_stats(True)
     r.reset_ray_counts()
     step()
@@ -172,6 +197,18 @@ def main():
     rays_per_launch = counts.closest / max(i_launches, 1)
     avg_ms = i_ms / max(i_launches, 1)
     achieved = (rays_per_launch * b_ray) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # the same kernel with nothing co-running (one extra untimed step on renderer 0): with --pipeline 2 the
+    # kernels of two frames share the chip, which lengthens each launch although the step gets shorter
+    r.reset_ray_counts()
+    r.enable_timings(True)
+    step_no[0] = 0
+    step()
+    fence()
+    s_ms, s_launches = r.timings()["intersection"]
+    r.enable_timings(False)
+    s_rays = r.ray_counts().closest / max(s_launches, 1)
+    s_avg = s_ms / max(s_launches, 1)
+    solo = (s_rays * b_ray) / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -201,7 +238,8 @@ def main():
             "ms_per_frame": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": i_launches, "rays_per_launch": rays_per_launch,
+                         "avg_launch_ms": avg_ms, "launches": i_launches, "frames_in_flight": P,
+                         "solo": {"achieved": solo, "frac": solo / HBM_PEAK_GBS, "avg_launch_ms": s_avg, "launches": s_launches}, "rays_per_launch": rays_per_launch,
                          "bytes_per_ray": b_ray, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar},
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in timings.items()},
@@ -216,7 +254,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    r.close()
+    for rr in rs:
+        rr.close()
     probe.close()
     sg.close()
     dev.close()

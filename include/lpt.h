@@ -332,6 +332,9 @@ int lpt_renderer_reset_ray_counts(lpt_renderer *r);
 /* count BVH nodes visited / triangles tested per ray (slower kernel variant) */
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag);
 int lpt_renderer_synchronize(lpt_renderer *r);
+/* The HIP stream (void*: a hipStream_t) this renderer enqueues on.  Each renderer owns one, so two
+ * renderers on one device pipeline consecutive frames; the collective layer orders its reduce on it. */
+int lpt_renderer_stream(lpt_renderer *r, void **hip_stream);
 
 #ifdef __cplusplus
 }

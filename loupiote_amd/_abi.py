@@ -121,6 +121,7 @@ SIGNATURES = {
     "lpt_renderer_reset_ray_counts": (_i, [_vp]),
     "lpt_renderer_enable_stats": (_i, [_vp, _i]),
     "lpt_renderer_synchronize": (_i, [_vp]),
+    "lpt_renderer_stream": (_i, [_vp, _pvp]),
 }
 
 _LIB = None

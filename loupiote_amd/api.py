@@ -381,6 +381,11 @@ class Renderer:
         _check(A.lib().lpt_renderer_get_timings(self._h, arr, C.byref(n)))
         return {arr[i].label.decode(): (arr[i].ms, arr[i].launches) for i in range(min(n.value, 8))}
 
+    def stream(self):
+        s = C.c_void_p()
+        _check(A.lib().lpt_renderer_stream(self._h, C.byref(s)))
+        return s.value
+
     def synchronize(self):
         _check(A.lib().lpt_renderer_synchronize(self._h))
 

@@ -49,6 +49,8 @@ static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "s
 
 struct lpt_renderer {
     lpt_device *dev = nullptr;
+    hipStream_t stream = nullptr;   // every renderer enqueues on its OWN stream, so two renderers pipeline
+                                    // consecutive frames (and a frame's collective overlaps the next frame)
     uint32_t req_w = 0, req_h = 0, w = 0, h = 0;
     float downsample = 0.5f;
     const lpt_scene_gpu *sg = nullptr;
@@ -346,7 +348,7 @@ static void free_denoiser(lpt_renderer *r) {
 static int ensure_denoiser(lpt_renderer *r) {
     if (r->den_temp) return LPT_OK;
     const size_t n = (size_t)r->w * r->h;
-    hipStream_t s = r->dev->stream;
+    hipStream_t s = r->stream;
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&r->den_gbuf[k], sizeof(uint4) * n));
         HIP_TRY(hipMalloc(&r->den_rad[k], sizeof(float4) * n));
@@ -403,7 +405,7 @@ static int alloc_ray_buffers(lpt_renderer *r) {
 
 static int alloc_frame_buffers(lpt_renderer *r) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     free_frame_buffers(r);
     if (!r->w || !r->h) return LPT_OK;
     uint32_t tiles_x, n_tiles, n_slots;
@@ -414,7 +416,7 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     if (st != LPT_OK) return st;
     HIP_TRY(hipMalloc(&r->accum, sizeof(float4) * px));
     HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
-    HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->dev->stream));
+    HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->stream));
     return LPT_OK;
 }
 
@@ -423,6 +425,10 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     HIP_TRY(hipSetDevice(dev->ordinal));
     lpt_renderer *r = new lpt_renderer();
     r->dev = dev;
+    {
+        hipError_t se = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
+    }
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
@@ -447,12 +453,13 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
 int lpt_renderer_destroy(lpt_renderer *r) {
     if (!r) return LPT_OK;
     hipSetDevice(r->dev->ordinal);
-    hipStreamSynchronize(r->dev->stream);
+    hipStreamSynchronize(r->stream);
     free_frame_buffers(r);
     if (r->ctr) hipFree(r->ctr);
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->n_slots_host) hipHostFree(r->n_slots_host);
+    if (r->stream) hipStreamDestroy(r->stream);
     if (r->noise) hipFree(r->noise);
     if (r->ev_start) {
         for (int i = 0; i < lpt_renderer::kRing * lpt_renderer::kMaxEvents; ++i) { hipEventDestroy(r->ev_start[i]); hipEventDestroy(r->ev_stop[i]); }
@@ -546,7 +553,7 @@ int lpt_renderer_get_frame_state(const lpt_renderer *r, uint32_t *fc, uint32_t *
 int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t w, uint32_t h, uint32_t row_bytes) {
     if (!r || !rgba8 || !w || !h || row_bytes < w * 4u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_upload_noise: bad arguments");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->noise) { hipFree(r->noise); r->noise = nullptr; }
     HIP_TRY(hipMalloc(&r->noise, (size_t)w * h * 4));
     HIP_TRY(hipMemcpy2D(r->noise, (size_t)w * 4, rgba8, row_bytes, (size_t)w * 4, h, hipMemcpyHostToDevice));
@@ -578,7 +585,7 @@ int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
         for (int i = 0; i < total; ++i) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
     }
     if (flag) {  // (re)start accumulating
-        HIP_TRY(hipStreamSynchronize(r->dev->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
         for (int k = 0; k < lpt_renderer::kRing; ++k) r->ev_count[k] = 0;
         for (int i = 0; i < 8; ++i) { r->stage_ms[i] = 0.0; r->stage_launches[i] = 0; }
     }
@@ -606,13 +613,13 @@ static inline void stage_begin(lpt_renderer *r, int stage) {
     const int slot = cur_slot(r);
     if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
     r->ev_stage[slot][r->ev_count[slot]] = stage;
-    hipEventRecord(r->ev_start[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->dev->stream);
+    hipEventRecord(r->ev_start[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->stream);
 }
 static inline void stage_end(lpt_renderer *r) {
     if (!r->timings) return;
     const int slot = cur_slot(r);
     if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
-    hipEventRecord(r->ev_stop[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->dev->stream);
+    hipEventRecord(r->ev_stop[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->stream);
     r->ev_count[slot]++;
 }
 
@@ -634,7 +641,7 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
     if (!r->w || !r->h) return LPT_OK;
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    hipStream_t s = r->dev->stream;
+    hipStream_t s = r->stream;
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
 
     FrameParams p;
@@ -758,10 +765,16 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     return LPT_OK;
 }
 
+int lpt_renderer_stream(lpt_renderer *r, void **stream) {
+    if (!r || !stream) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_stream: null");
+    *stream = (void *)r->stream;
+    return LPT_OK;
+}
+
 int lpt_renderer_synchronize(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_synchronize: null");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     return LPT_OK;
 }
 
@@ -777,9 +790,9 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);
     const uint32_t n = r->w * r->h;
-    if (e == hipSuccess) { hipLaunchKernelGGL(k_resolve, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, r->scratch, n); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->dev->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(r->dev->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_resolve, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->accum, r->scratch, n); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
     return LPT_OK;
 }
@@ -791,14 +804,14 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
     const uint32_t n = r->w * r->h;
     if (e == hipSuccess) {
         if ((r->mode == LPT_BLIT_GBUFFER || r->mode == LPT_BLIT_MOTION) && r->den_temp)  // debug views (renderer.rs:574-586)
-            hipLaunchKernelGGL(k_debug_view, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->den_gbuf[r->den_cur], r->den_motion,
+            hipLaunchKernelGGL(k_debug_view, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->den_gbuf[r->den_cur], r->den_motion,
                                (uchar4 *)r->scratch, (int)r->w, (int)r->h, r->mode);
         else
-            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->dev->stream, r->accum, (uchar4 *)r->scratch, n);
+            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->accum, (uchar4 *)r->scratch, n);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->dev->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(r->dev->stream);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
     return LPT_OK;
 }
@@ -816,7 +829,7 @@ int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_denoiser: null");
     if (!r->den_temp) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no denoising frame has been traced");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     const size_t n = (size_t)r->w * r->h;
     const int c = r->den_cur;
     if (gbuffer) HIP_TRY(hipMemcpy(gbuffer, r->den_gbuf[c], sizeof(uint4) * n, hipMemcpyDeviceToHost));
@@ -830,8 +843,8 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     if (!r || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_ray_counts: null");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     Totals t;
-    HIP_TRY(hipMemcpyAsync(&t, r->totals, sizeof t, hipMemcpyDeviceToHost, r->dev->stream));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipMemcpyAsync(&t, r->totals, sizeof t, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     out->closest = t.closest; out->shadow = t.shadow; out->shaded = t.shaded; out->nodes = t.nodes; out->tris = t.tris;
     out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
     return LPT_OK;
@@ -840,14 +853,14 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
 int lpt_renderer_reset_ray_counts(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_reset_ray_counts: null");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipMemsetAsync(r->totals, 0, sizeof(Totals), r->dev->stream));
+    HIP_TRY(hipMemsetAsync(r->totals, 0, sizeof(Totals), r->stream));
     return LPT_OK;
 }
 
 int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count) {
     if (!r || !inout_count) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_timings: null");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    HIP_TRY(hipStreamSynchronize(r->dev->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
     lpt_timing acc[ST_COUNT];
     if (r->ev_start) for (int k = 0; k < lpt_renderer::kRing; ++k) harvest_slot(r, k);
     for (int i = 0; i < ST_COUNT; ++i) {
