@@ -223,6 +223,10 @@ int lpt_load_gltf(lpt_scene *scene, const uint8_t *data, size_t size);
 /* replaces: loaders::load_gltf_path (gltf.rs:158-161) */
 int lpt_load_gltf_path(lpt_scene *scene, const char *path);
 
+/* replaces: the `image::ImageBuffer::save` half of ApplicationContext::save_screenshot
+ * (crates/standalone/src/app.rs:172-187): writes RGBA8 rows (e.g. from lpt_renderer_read_pixels) as a PNG. */
+int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, size_t row_bytes);
+
 /* ---- SceneGPU / ProbeGPU --------------------------------------------------
  * replaces: SceneGPU::new_from_scene(&Scene,&Device,&Queue)
  * (crates/lib/src/scene.rs:151-188).  Bakes every instance into world space,

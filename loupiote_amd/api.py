@@ -408,6 +408,12 @@ class loaders:
         _check(A.lib().lpt_load_gltf_path(scene._h, str(path).encode()))
 
 
+def save_screenshot(renderer, path):
+    """ApplicationContext::save_screenshot (crates/standalone/src/app.rs:172-187): read_pixels -> PNG file"""
+    px = renderer.read_pixels()
+    _check(A.lib().lpt_write_png(str(path).encode(), A.ptr(px), px.shape[1], px.shape[0], px.shape[1] * 4))
+
+
 class CameraController:
     """Convention-only mirror of crates/standalone/src/camera.rs:46-116: `update()` returns the
     camera-to-world Mat4 = T(origin) * [right up direction W] (column-major, 16 floats)."""

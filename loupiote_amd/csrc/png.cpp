@@ -2,6 +2,9 @@
 // The reference decodes images through the `gltf` crate's `image` import and then
 // expands to RGBA8 leaving missing channels at 0 (crates/lib/src/loaders/gltf.rs:12-44);
 // the same expansion rule is applied here.  Non-interlaced, 8/16-bit, colour types 0/2/3/4/6.
+#include <algorithm>
+#include <cstdio>
+
 #include "common.h"
 
 namespace lpt {
@@ -202,3 +205,78 @@ bool decode_png(const uint8_t *data, size_t size, Image &out) {
 }
 
 }  // namespace lpt
+
+// ---------------------------------------------------------------------------- PNG writer
+// Headless stand-in for the app's `save_screenshot` (reference crates/standalone/src/app.rs:172-187:
+// read_pixels -> image::ImageBuffer::save).  RGBA8, filter 0, zlib "stored" blocks (no compression).
+namespace lpt {
+namespace {
+uint32_t crc_table[256];
+bool crc_ready = false;
+uint32_t crc32(uint32_t crc, const uint8_t *p, size_t n) {
+    if (!crc_ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = crc_table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+void put32(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void chunk(std::vector<uint8_t> &out, const char *type, const std::vector<uint8_t> &body) {
+    put32(out, (uint32_t)body.size());
+    const size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body.begin(), body.end());
+    put32(out, crc32(0, &out[start], out.size() - start));
+}
+}  // namespace
+
+bool encode_png(const uint8_t *rgba8, uint32_t w, uint32_t h, size_t row_bytes, std::vector<uint8_t> &out) {
+    if (!rgba8 || !w || !h || row_bytes < (size_t)w * 4) return false;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    out.assign(sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, w); put32(ihdr, h);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr);
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)w * 4 + 1) * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba8 + (size_t)y * row_bytes, rgba8 + (size_t)y * row_bytes + (size_t)w * 4);
+    }
+    std::vector<uint8_t> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    size_t off = 0;
+    while (off < raw.size()) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)off, raw.begin() + (long)(off + n));
+        off += n;
+    }
+    put32(z, (b << 16) | a);
+    chunk(out, "IDAT", z);
+    chunk(out, "IEND", {});
+    return true;
+}
+}  // namespace lpt
+
+extern "C" int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, size_t row_bytes) {
+    if (!path) return lpt::fail(LPT_ERR_INVALID_ARG, "lpt_write_png: null path");
+    std::vector<uint8_t> png;
+    if (!lpt::encode_png(rgba8, width, height, row_bytes, png)) return lpt::fail(LPT_ERR_INVALID_ARG, "lpt_write_png: bad image");
+    FILE *f = fopen(path, "wb");
+    if (!f) return lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: cannot open %s for writing", path);
+    const bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
+    fclose(f);
+    return ok ? LPT_OK : lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: short write to %s", path);
+}
