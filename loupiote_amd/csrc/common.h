@@ -70,4 +70,7 @@ void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3],
 // png.cpp
 bool decode_png(const uint8_t *data, size_t size, Image &out);
 
+// jpeg.cpp
+bool decode_jpeg(const uint8_t *data, size_t size, Image &out);
+
 }  // namespace lpt

@@ -181,7 +181,7 @@ void decode_image(const Doc &d, const Json &img, Image &out) {
         raw = base64_decode(u.c_str() + comma + 1, u.size() - comma - 1);
         p = raw.data(); n = raw.size();
     } else bad("external images are not supported by load_gltf(&[u8])");
-    if (!decode_png(p, n, out)) bad("image is not a decodable PNG (JPEG is not supported)");
+    if (!decode_png(p, n, out) && !decode_jpeg(p, n, out)) bad("image is neither a decodable PNG nor a baseline JPEG");
 }
 
 void load(lpt_scene *scene, const uint8_t *data, size_t size) {

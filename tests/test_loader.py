@@ -197,3 +197,52 @@ def test_png_decoder_matches_pil():
         want = np.zeros(arr.shape[:2] + (4,), np.uint8)
         want[..., : (arr.shape[2] if arr.ndim == 3 else 1)] = arr if arr.ndim == 3 else arr[..., None]
         assert np.array_equal(got, want)
+
+
+def _smooth_rgb(h=97, w=131):
+    y, x = np.mgrid[0:h, 0:w]
+    return np.stack([127 + 100 * np.sin(x / 9.0) * np.cos(y / 13.0), 127 + 90 * np.cos(x / 17.0 + y / 11.0),
+                     60 + x * 1.2 + y * 0.3], axis=-1).clip(0, 255).astype(np.uint8)
+
+
+def _jpeg(arr, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("kw,mean_tol,max_tol", [
+    (dict(quality=92, subsampling=0), 0.1, 4),                          # 4:4:4: only IDCT rounding differs
+    (dict(quality=92, subsampling=1), 2.5, 16),                         # 4:2:2: + replicate vs fancy upsampling
+    (dict(quality=92, subsampling=2), 3.0, 24),                         # 4:2:0
+    (dict(quality=60, subsampling=0, restart_marker_blocks=5), 0.2, 4), # DRI / RSTn
+    (dict(quality=85, subsampling=2, restart_marker_rows=1), 3.0, 24),
+])
+def test_jpeg_decoder_close_to_pil(kw, mean_tol, max_tol):
+    """Baseline JPEG textures (DamagedHelmet / Sponza): the product decoder against libjpeg (PIL) — float IDCT
+    and replicated chroma, so a stated tolerance instead of bit-exactness (SPEC §14.5)."""
+    from PIL import Image
+    raw = _jpeg(_smooth_rgb(), **kw)
+    ref = np.asarray(Image.open(io.BytesIO(raw)).convert("RGB")).astype(int)
+    s = lp.Scene()
+    lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[raw], textures=[0]), s)
+    got = s.image(0)
+    assert got.shape == (97, 131, 4) and np.all(got[..., 3] == 0)       # RGB -> RGBA with alpha 0 (gltf.rs:26-38)
+    d = np.abs(got[..., :3].astype(int) - ref)
+    assert d.mean() < mean_tol and d.max() <= max_tol
+
+
+def test_jpeg_grey_and_unsupported_modes():
+    from PIL import Image
+    grey = _smooth_rgb()[..., 0]
+    raw = _jpeg(grey, quality=90)
+    s = lp.Scene()
+    lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[raw], textures=[0]), s)
+    got = s.image(0)
+    ref = np.asarray(Image.open(io.BytesIO(raw))).astype(int)
+    assert np.abs(got[..., 0].astype(int) - ref).max() <= 2 and np.all(got[..., 1:] == 0)   # R8 -> (r,0,0,0)
+    for broken in (_jpeg(_smooth_rgb(), progressive=True), raw[: len(raw) // 2], raw[:20]):
+        with pytest.raises(lp.Error) as e:
+            lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[broken], textures=[0]), lp.Scene())
+        assert e.value.kind == "FileNotFound"
