@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <memory>
 
 #include "common.h"
 
@@ -58,12 +60,14 @@ struct Box {
 
 struct Ref { Box box; float c[3]; uint32_t prim; };
 
-struct BuildNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0; };
+// count != 0 marks a leaf of the binary tree; [pfirst, pfirst + pcount) is the ref range of any node's subtree
+struct BuildNode { Box box; int32_t left = -1, right = -1; uint32_t first = 0, count = 0, pfirst = 0, pcount = 0; };
 
 struct Builder {
     std::vector<Ref> refs;
     std::vector<BuildNode> nodes;
     uint32_t max_depth = 0;
+    uint32_t leaf_max = kLeafMax;  // leaf size of the BINARY tree (1 when the collapse forms the leaves itself)
 
     static uint32_t ceil_log2(uint32_t x) { uint32_t l = 0; while ((1u << l) < x) ++l; return l; }
 
@@ -73,11 +77,13 @@ struct Builder {
         Box box, cbox;
         for (uint32_t i = first; i < first + count; ++i) { box.grow(refs[i].box); cbox.grow(refs[i].c); }
         nodes[id].box = box;
+        nodes[id].pfirst = first;
+        nodes[id].pcount = count;
         max_depth = std::max(max_depth, depth);
-        if (count <= kLeafMax) { nodes[id].first = first; nodes[id].count = count; return id; }
+        if (count <= leaf_max) { nodes[id].first = first; nodes[id].count = count; return id; }
 
         // depth budget: below this node we may still need ceil(log2(count/leaf)) median levels
-        const uint32_t need = ceil_log2((count + kLeafMax - 1) / kLeafMax);
+        const uint32_t need = ceil_log2((count + leaf_max - 1) / leaf_max);
         const bool force_median = depth + need + 1 >= kMaxDepth;
 
         int best_axis = -1, best_split = -1;
@@ -185,6 +191,65 @@ void bake(const lpt_scene &s, Accel &out) {
     }
 }
 
+
+// SAH-optimal collapse of the binary tree into 8-wide nodes (Ylitie, Karras & Laine 2017, §4.1).
+// C(n,i) = cheapest way to represent the subtree of binary node n by at most i roots, a root being
+// either an 8-wide node or a leaf of <= kLeafMax triangles:
+//   C(n,1) = min( A_n * P_n * c_prim  [P_n <= kLeafMax],  D(n,8) + A_n * c_node )
+//   C(n,i) = min( D(n,i), C(n,i-1) ),   D(n,j) = min_{0<k<j} C(left,k) + C(right,j-k)
+// The binary tree is built down to single triangles so that the leaves are formed here.
+struct Kid { int32_t node; bool leaf; };
+struct Collapse {
+    static constexpr float kNodeCost = 1.0f, kPrimCost = 0.3f;
+    const std::vector<BuildNode> &n;
+    std::vector<float> C;        // [7 * node + i - 1]
+    std::vector<uint8_t> how;    // i == 1: 1 = 8-wide node, 0 = leaf;  i >= 2: 0 = same as C(n,i-1), else k of D(n,i)
+    std::vector<uint8_t> k8;     // k of D(n,8), used when n becomes an 8-wide node
+    explicit Collapse(const std::vector<BuildNode> &nodes) : n(nodes), C(7 * nodes.size()), how(7 * nodes.size(), 0), k8(nodes.size(), 0) {
+        for (size_t id = nodes.size(); id-- > 0;) {
+            const BuildNode &b = n[id];
+            const float A = b.box.half_area();
+            float *c = &C[7 * id];
+            const float leaf = b.pcount <= kLeafMax ? A * (float)b.pcount * kPrimCost : 1e30f;
+            if (b.count) { for (int i = 0; i < 7; ++i) c[i] = leaf; continue; }
+            const float *l = &C[7 * (size_t)b.left], *r = &C[7 * (size_t)b.right];
+            float D[9];
+            uint8_t Dk[9];
+            for (int j = 2; j <= 8; ++j) {
+                D[j] = 1e30f; Dk[j] = 1;
+                for (int k = 1; k < j; ++k) {
+                    const float v = l[k - 1] + r[j - k - 1];
+                    if (v < D[j]) { D[j] = v; Dk[j] = (uint8_t)k; }
+                }
+            }
+            k8[id] = Dk[8];
+            const float inner = D[8] + A * kNodeCost;
+            c[0] = std::min(leaf, inner);
+            how[7 * id] = inner < leaf ? 1 : 0;
+            for (int i = 2; i <= 7; ++i) {
+                if (D[i] < c[i - 2]) { c[i - 1] = D[i]; how[7 * id + i - 1] = Dk[i]; }
+                else { c[i - 1] = c[i - 2]; how[7 * id + i - 1] = 0; }
+            }
+        }
+    }
+    void roots(int32_t m, int i, Kid *out, int &nk) const {   // the <= i roots C(m,i) stands for
+        if (n[m].count) { out[nk++] = {m, true}; return; }
+        while (i > 1 && how[7 * (size_t)m + i - 1] == 0) --i;
+        if (i == 1) { out[nk++] = {m, how[7 * (size_t)m] == 0}; return; }
+        const int k = how[7 * (size_t)m + i - 1];
+        roots(n[m].left, k, out, nk);
+        roots(n[m].right, i - k, out, nk);
+    }
+    int children(int32_t m, Kid *out) const {                  // m is an 8-wide node: its <= 8 children
+        int nk = 0;
+        if (n[m].count) { out[nk++] = {m, true}; return nk; }
+        const int k = k8[m];
+        roots(n[m].left, k, out, nk);
+        roots(n[m].right, 8 - k, out, nk);
+        return nk;
+    }
+};
+
 // Triangle boxes are padded a little so that the box test stays conservative with
 // respect to the Woop test's own rounding (the slab test adds its own ulp margins).
 Box padded_box(const lpt_vertex *v) {
@@ -238,7 +303,14 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         r.prim = t;
     }
     b.nodes.reserve(2 * (size_t)n);
+    const char *mode = getenv("LPT_BVH_COLLAPSE");  // "greedy" keeps the round-1 builder for A/B runs
+    const bool use_dp = !(mode && strcmp(mode, "greedy") == 0);
+    b.leaf_max = use_dp ? 1u : kLeafMax;
     b.build(0, n, 0);
+    std::unique_ptr<Collapse> collapse;
+    if (use_dp) collapse.reset(new Collapse(b.nodes));
+    uint32_t stat_kids[9] = {0}, stat_leaf_tris[kLeafMax + 1] = {0};
+    double sah = 0.0;
 
     // ---- collapse the binary tree into 8-wide nodes (breadth first, so siblings are adjacent)
     struct Pending { int32_t bvh2; uint32_t depth; };
@@ -252,27 +324,35 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         const int32_t root = queue[w].bvh2;
         const uint32_t depth = queue[w].depth;
         max_depth = std::max(max_depth, depth);
-        // children: open the inner member with the largest surface area until 8 (or none is left)
-        int32_t kids[8];
+        Kid kids[8];
         int nk = 0;
-        if (b.nodes[root].count) kids[nk++] = root;  // the whole tree is one leaf
-        else { kids[nk++] = b.nodes[root].left; kids[nk++] = b.nodes[root].right; }
-        while (nk < 8) {
-            int best = -1;
-            float best_area = -1.f;
-            for (int i = 0; i < nk; ++i)
-                if (!b.nodes[kids[i]].count) {
-                    const float a = b.nodes[kids[i]].box.half_area();
-                    if (a > best_area) { best_area = a; best = i; }
-                }
-            if (best < 0) break;
-            const int32_t open = kids[best];
-            kids[best] = b.nodes[open].left;
-            kids[nk++] = b.nodes[open].right;
+        if (collapse) {
+            // the root may itself be a leaf-sized subtree: one node with one leaf child
+            if (w == 0 && !b.nodes[root].count && collapse->how[7 * (size_t)root] == 0) kids[nk++] = {root, true};
+            else nk = collapse->children(root, kids);
+        } else {
+            // greedy: open the inner member with the largest surface area until 8 (or none is left)
+            if (b.nodes[root].count) kids[nk++] = {root, true};  // the whole tree is one leaf
+            else { kids[nk++] = {b.nodes[root].left, false}; kids[nk++] = {b.nodes[root].right, false}; }
+            for (int i = 0; i < nk; ++i) kids[i].leaf = b.nodes[kids[i].node].count != 0;
+            while (nk < 8) {
+                int best = -1;
+                float best_area = -1.f;
+                for (int i = 0; i < nk; ++i)
+                    if (!kids[i].leaf) {
+                        const float a = b.nodes[kids[i].node].box.half_area();
+                        if (a > best_area) { best_area = a; best = i; }
+                    }
+                if (best < 0) break;
+                const int32_t open = kids[best].node;
+                kids[best] = {b.nodes[open].left, b.nodes[b.nodes[open].left].count != 0};
+                kids[nk++] = {b.nodes[open].right, b.nodes[b.nodes[open].right].count != 0};
+            }
         }
+        stat_kids[nk]++;
         // node box = union of the children (they are padded already)
         Box nb;
-        for (int i = 0; i < nk; ++i) nb.grow(b.nodes[kids[i]].box);
+        for (int i = 0; i < nk; ++i) nb.grow(b.nodes[kids[i].node].box);
         // slot assignment: slot s stands for the diagonal direction ds = (+-1,+-1,+-1) (bit set = +);
         // greedily give every child the free slot its offset from the node centre points to most.
         // Traversal visits slots in the order (slot XOR ray octant), i.e. roughly front to back.
@@ -285,7 +365,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
             int bi = 0, bs = 0;
             for (int i = 0; i < nk; ++i) {
                 if (kid_done[i]) continue;
-                const Box &cb = b.nodes[kids[i]].box;
+                const Box &cb = b.nodes[kids[i].node].box;
                 const float off[3] = {0.5f * (cb.lo[0] + cb.hi[0]) - cx[0], 0.5f * (cb.lo[1] + cb.hi[1]) - cx[1], 0.5f * (cb.lo[2] + cb.hi[2]) - cx[2]};
                 for (int sl = 0; sl < 8; ++sl) {
                     if (slot_used[sl]) continue;
@@ -328,33 +408,44 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
                 *q[3] = *q[4] = *q[5] = 0;
                 continue;
             }
-            const BuildNode &c = b.nodes[kids[i]];
+            const BuildNode &c = b.nodes[kids[i].node];
             for (int a = 0; a < 3; ++a) {
                 const double lo = std::floor(((double)c.box.lo[a] - (double)nb.lo[a]) / scale[a]);
                 const double hi = std::ceil(((double)c.box.hi[a] - (double)nb.lo[a]) / scale[a]);
                 *q[a] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
                 *q[3 + a] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
             }
-            if (c.count) {
+            if (kids[i].leaf) {
                 // leaf child: unary triangle count in the top 3 bits, offset from tri_base in the low 5
-                node.meta[sl] = (uint8_t)((((1u << c.count) - 1u) << 5) | tri_off);
-                for (uint32_t t = 0; t < c.count; ++t) {
-                    const uint32_t prim = b.refs[c.first + t].prim;
+                node.meta[sl] = (uint8_t)((((1u << c.pcount) - 1u) << 5) | tri_off);
+                stat_leaf_tris[c.pcount]++;
+                sah += (double)c.box.half_area() * c.pcount * Collapse::kPrimCost;
+                for (uint32_t t = 0; t < c.pcount; ++t) {
+                    const uint32_t prim = b.refs[c.pfirst + t].prim;
                     const lpt_vertex *v = &out.tri_verts[3 * (size_t)prim];
                     WoopTri wt;
                     woop_from_triangle(v[0].position, v[1].position, v[2].position, wt);
                     out.woop.push_back(wt);
                     out.leaf_prim.push_back(prim);
                 }
-                tri_off += c.count;
+                tri_off += c.pcount;
             } else {
                 node.meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
                 node.imask |= (uint8_t)(1u << sl);
-                queue.push_back({kids[i], depth + 1});
+                queue.push_back({kids[i].node, depth + 1});
             }
         }
+        sah += (double)nb.half_area() * Collapse::kNodeCost;
         if (out.nodes.size() < queue.size()) out.nodes.resize(queue.size());
         out.nodes[w] = node;
+    }
+    if (getenv("LPT_BVH_STATS")) {
+        fprintf(stderr, "[lpt bvh] %s: %zu nodes, depth %u, SAH %.3f, children/node:", use_dp ? "dp" : "greedy", out.nodes.size(), max_depth,
+                sah / std::max((double)b.nodes[0].box.half_area(), 1e-30));
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %u", stat_kids[i]);
+        fprintf(stderr, "; tris/leaf:");
+        for (uint32_t i = 1; i <= kLeafMax; ++i) fprintf(stderr, " %u", stat_leaf_tris[i]);
+        fprintf(stderr, "\n");
     }
     out.max_depth = max_depth;
     if (out.woop.size() != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %zu of %u triangles referenced", out.woop.size(), n);

@@ -220,7 +220,9 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
     if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
     DScene &d = sg->d;
     d.nodes = (const DNode8 *)sg->nodes;
-    d.stack_entries = acc.max_depth + 1u;
+    // a stack entry holds the unvisited siblings below a node at depth 1..max_depth-1 (the root's own group has one
+    // member and is never pushed, the deepest nodes have no inner children): max_depth-1 entries are enough
+    d.stack_entries = acc.max_depth > 2u ? acc.max_depth - 1u : 1u;
     d.woop = (const float4 *)sg->woop;
     d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     d.tri_verts = (const float4 *)sg->tri_verts;

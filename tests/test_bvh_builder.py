@@ -1,0 +1,84 @@
+"""Host logic: the 8-wide BVH builder (loupiote_amd/csrc/bvh.cpp) checked on the CPU by tests/tools/bvh_check.cpp,
+a test-only walker of the Node8 format: random rays must find exactly the brute-force closest hit (t and prim),
+every triangle must be referenced once, for both collapse modes and for degenerate soups."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "loupiote_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def bvh_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bvh") / "bvh_check")
+    src = [os.path.join(ROOT, "tests", "tools", "bvh_check.cpp")] + [os.path.join(CSRC, f) for f in
+                                                                      ("scene.cpp", "bvh.cpp", "png.cpp", "jpeg.cpp", "gltf.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe] + src + ["-lpthread"], check=True)
+    return exe
+
+
+def run(exe, tmp_path, tris, rays, mode=None, eye=None):
+    path = str(tmp_path / "soup.bin")
+    tris = np.ascontiguousarray(tris, "<f4").reshape(-1, 9)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(tris)))
+        f.write(tris.tobytes())
+    env = dict(os.environ)
+    if mode:
+        env["LPT_BVH_COLLAPSE"] = mode
+    cmd = [exe, path, str(rays), "1"] + ([str(v) for v in eye] if eye else [])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0, (out, p.stderr)
+    return out
+
+
+def random_soup(rng, n, extent=10.0, size=0.6):
+    c = rng.uniform(-extent, extent, (n, 1, 3))
+    return (c + rng.normal(0, size, (n, 3, 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["dp", "greedy"])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 9, 64, 3000])
+def test_random_soups_match_brute_force(bvh_check, tmp_path, mode, n):
+    rng = np.random.default_rng(n)
+    out = run(bvh_check, tmp_path, random_soup(rng, n), 4000, mode)
+    assert out["triangles"] == n and out["mismatches"] == 0 and out["bad_refs"] == 0
+    assert out["hits"] > 0 or n < 9
+
+
+def test_degenerate_soups(bvh_check, tmp_path):
+    rng = np.random.default_rng(7)
+    one = random_soup(rng, 1)
+    same = np.repeat(one, 200, axis=0)                                   # 200 coincident triangles: tie rule -> lowest prim
+    out = run(bvh_check, tmp_path, same, 2000)
+    assert out["mismatches"] == 0 and out["bad_refs"] == 0 and out["depth"] <= 30
+    flat = random_soup(rng, 500)
+    flat[..., 1] = 0.25                                                   # coplanar: zero-extent axis, exponent clamp
+    out = run(bvh_check, tmp_path, flat, 4000)
+    assert out["mismatches"] == 0 and out["bad_refs"] == 0
+    sliver = random_soup(rng, 300, extent=1000.0, size=1e-3)             # tiny triangles far apart
+    sliver[::2] *= 1e-3
+    out = run(bvh_check, tmp_path, sliver, 4000)
+    assert out["mismatches"] == 0 and out["bad_refs"] == 0
+    out = run(bvh_check, tmp_path, np.zeros((0, 9), np.float32), 100)     # empty scene: one empty node, nothing hit
+    assert out["triangles"] == 0 and out["hits"] == 0 and out["nodes"] == 1
+
+
+def test_grid_mesh_quality(bvh_check, tmp_path):
+    """a tessellated wall: the SAH-optimal collapse fills nodes (fewer, fuller nodes than the greedy one) and
+    does not visit more nodes per ray"""
+    n = 96
+    u, v = np.meshgrid(np.linspace(-5, 5, n + 1), np.linspace(-5, 5, n + 1), indexing="xy")
+    p = np.stack([u, v, 0.3 * np.sin(u) * np.cos(v)], -1).astype(np.float32)
+    a, b, c, d = p[:-1, :-1], p[:-1, 1:], p[1:, :-1], p[1:, 1:]
+    tris = np.concatenate([np.stack([a, b, d], -2), np.stack([a, d, c], -2)]).reshape(-1, 9)
+    dp = run(bvh_check, tmp_path, tris, 20000, "dp", eye=(0, 0, 8))
+    gr = run(bvh_check, tmp_path, tris, 20000, "greedy", eye=(0, 0, 8))
+    assert dp["mismatches"] == gr["mismatches"] == 0 and dp["hits"] == gr["hits"]
+    assert dp["nodes"] < 0.8 * gr["nodes"] and dp["nodes_per_ray"] <= 1.02 * gr["nodes_per_ray"]
