@@ -241,7 +241,9 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": i_launches, "frames_in_flight": P,
                          "solo": {"achieved": solo, "frac": solo / HBM_PEAK_GBS, "avg_launch_ms": s_avg, "launches": s_launches}, "rays_per_launch": rays_per_launch,
                          "bytes_per_ray": b_ray, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
-                         "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar},
+                         "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
+                         "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
+                                  "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in timings.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},

@@ -130,6 +130,11 @@ typedef struct lpt_ray_counts {
     uint64_t tris;    /* closest-hit kernel: triangles tested  (stats enabled only) */
     uint64_t shadow_nodes; /* shadow kernel: nodes visited (stats enabled only)     */
     uint64_t shadow_tris;  /* shadow kernel: triangles tested (stats enabled only)  */
+    /* closest-hit kernel, stats enabled only: wave utilisation of the persistent traversal loop */
+    uint64_t wave_steps;   /* loop iterations summed over waves                        */
+    uint64_t live_lanes;   /* lanes carrying a ray, summed over those iterations        */
+    uint64_t node_lanes;   /* lanes that entered the node test                         */
+    uint64_t tri_lanes;    /* lanes that ran a triangle test                           */
 } lpt_ray_counts;
 
 typedef struct lpt_timing {

@@ -42,7 +42,8 @@ class AccelStats(C.Structure):
 
 
 class RayCounts(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris", "shadow_nodes", "shadow_tris")]
+    _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris", "shadow_nodes", "shadow_tris",
+                                             "wave_steps", "live_lanes", "node_lanes", "tri_lanes")]
 
 
 class Timing(C.Structure):

@@ -849,6 +849,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     HIP_TRY(hipStreamSynchronize(r->stream));
     out->closest = t.closest; out->shadow = t.shadow; out->shaded = t.shaded; out->nodes = t.nodes; out->tris = t.tris;
     out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
+    out->wave_steps = t.wave_steps; out->live_lanes = t.live_lanes; out->node_lanes = t.node_lanes; out->tri_lanes = t.tri_lanes;
     return LPT_OK;
 }
 

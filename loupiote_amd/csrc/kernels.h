@@ -61,8 +61,9 @@ struct FrameCounters {
     uint32_t shead[kMaxBounces * 8 * 32];
     uint32_t shaded[kMaxBounces];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
+    unsigned long long wave_steps, live_lanes, node_lanes, tri_lanes;  // closest-hit kernel, stats only
 };
-struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris; };
+struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes; };
 
 struct FrameParams {
     f3 origin, right, up, fwd;
@@ -210,8 +211,8 @@ __device__ __forceinline__ float safe_inv(float d) {
 //    stride kTraceBlock entries).
 //  * child boxes are decoded on the fly: t = q * (2^e / d) + (p - o) / d, near / far byte
 //    planes picked per axis from the ray's direction signs.  The [tn, tf] interval is widened
-//    by 4e-7 relative on both ends and triangle boxes are padded at build time, so the box
-//    tests are conservative; only the Woop test below decides hits (SPEC §7).
+//    by a bound on its own rounding error and triangle boxes are padded at build time, so the
+//    box tests are conservative; only the Woop test below decides hits (SPEC §7).
 //  * children sit in octant-ordered slots: visiting hit bits from the top after XOR-ing the
 //    slot with the inverted ray octant is an approximate front-to-back order.
 // Per-lane traversal state: one step() = at most one node visit plus one triangle test, so a
@@ -253,17 +254,23 @@ __device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *
         const DNode8 *n = sc.nodes + (rs.ng.x + rel);
         const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
         if (STATS) n_nodes++;
-        const float kNear = 0.9999996f, kFar = 1.0000004f;
         const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;
         const uint32_t oinv4 = rs.oinv * 0x01010101u;
+        // t(q) = q * a + b per axis; a is exact (power-of-two step times 1/d), b carries three roundings.
+        // |error of the computed t| <= 2^-24 * (4|b| + 510|a|), so widening b by eps = 2^-21 * (|b| + 255|a|)
+        // towards the outside on both ends keeps the test conservative wherever the ray starts.
+        const float kEps = 4.76837158203125e-7f;  // 2^-21
         const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * rs.ix;
         const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rs.iy;
         const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rs.iz;
         const float bx = (__uint_as_float(n0.x) - rs.o.x) * rs.ix;
         const float by = (__uint_as_float(n0.y) - rs.o.y) * rs.iy;
         const float bz = (__uint_as_float(n0.z) - rs.o.z) * rs.iz;
-        const float anx = ax * kNear, any_ = ay * kNear, anz = az * kNear, bnx = bx * kNear, bny = by * kNear, bnz = bz * kNear;
-        const float afx = ax * kFar, afy = ay * kFar, afz = az * kFar, bfx = bx * kFar, bfy = by * kFar, bfz = bz * kFar;
+        const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
+        const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
+        const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
+        const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
+        const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
         const float tbest = rs.best.t;
         uint32_t hitmask = 0u;
 #pragma unroll
@@ -281,12 +288,12 @@ __device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int sh = 8 * j;
-                const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), anx, bnx);
-                const float tny = fmaf((float)((qny >> sh) & 0xFFu), any_, bny);
-                const float tnz = fmaf((float)((qnz >> sh) & 0xFFu), anz, bnz);
-                const float tfx = fmaf((float)((qfx >> sh) & 0xFFu), afx, bfx);
-                const float tfy = fmaf((float)((qfy >> sh) & 0xFFu), afy, bfy);
-                const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), afz, bfz);
+                const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), ax, bnx);
+                const float tny = fmaf((float)((qny >> sh) & 0xFFu), ay, bny);
+                const float tnz = fmaf((float)((qnz >> sh) & 0xFFu), az, bnz);
+                const float tfx = fmaf((float)((qfx >> sh) & 0xFFu), ax, bfx);
+                const float tfy = fmaf((float)((qfy >> sh) & 0xFFu), ay, bfy);
+                const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), az, bfz);
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
                 if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, f
     puller_init(pl, &ctr->ihead[bounce * 8 * 32], ctr->qcount[bounce]);
     const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
     RayState rs;
     bool active = false;
     uint32_t ray = 0;
@@ -407,15 +415,28 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, f
                 pl.next = min(pl.end, pl.next + (uint32_t)(64 - n_active));
             } else if (n_active == 0) break;
         }
+        const uint32_t tris_before = n_tris;
+        if (STATS) {
+            w_steps++;
+            w_live += (uint32_t)__popcll(__ballot(active));
+            w_node += (uint32_t)__popcll(__ballot(active && rs.tg.y == 0u));
+        }
         if (active && ray_step<false, STATS>(sc, rs, stack, n_nodes, n_tris)) {
             intersect_lights(sc, rs.o, rs.d, rs.best);
             hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
             active = false;
         }
+        if (STATS) w_tri += (uint32_t)__popcll(__ballot(n_tris != tris_before));
     }
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
         atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        if (lane == 0) {
+            atomicAdd(&ctr->wave_steps, (unsigned long long)w_steps);
+            atomicAdd(&ctr->live_lanes, (unsigned long long)w_live);
+            atomicAdd(&ctr->node_lanes, (unsigned long long)w_node);
+            atomicAdd(&ctr->tri_lanes, (unsigned long long)w_tri);
+        }
     }
 }
 
@@ -896,6 +917,7 @@ __global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces
     for (uint32_t b = 0; b < bounces; ++b) { c += ctr->qcount[b]; s += ctr->shcount[b]; sh += ctr->shaded[b]; }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
+    tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
 }
 
 // mean radiance (a = 1 where sampled) and sRGB8 (SPEC §13.2)

@@ -74,7 +74,8 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
             float scale;
             memcpy(&scale, &bits, 4);
             const float A = scale * inv[k], B = (p[k] - o[k]) * inv[k];
-            an[k] = A * 0.9999996f; bn[k] = B * 0.9999996f; af[k] = A * 1.0000004f; bf[k] = B * 1.0000004f;
+            const float E = fmaf(fabsf(A), 255.0f, fabsf(B)) * 4.76837158203125e-7f;
+            an[k] = A; bn[k] = B - E; af[k] = A; bf[k] = B + E;
         }
         // visit order: kernels.h takes hit bits from the top, bit = 24 + (slot ^ oinv)
         struct Child { uint32_t key, node; };
@@ -159,6 +160,13 @@ int main(int argc, char **argv) {
             o[k] = from_eye ? (float)atof(argv[4 + k]) : lo[k] + (hi[k] - lo[k]) * U(rng);
             const float e = lo[k] + (hi[k] - lo[k]) * U(rng);
             d[k] = e - o[k];
+        }
+        if (n && (r & 3) == 2) {
+            // aim at a vertex / an edge point of a random triangle: the ray grazes that triangle's box,
+            // which is where a box test that is not conservative would lose the hit
+            const size_t t = (size_t)(U(rng) * n) % n;
+            const float w = (r & 4) ? U(rng) : 0.0f;
+            for (int k = 0; k < 3; ++k) d[k] = (pos[9 * t + k] * (1.0f - w) + pos[9 * t + 3 + k] * w) - o[k];
         }
         const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         if (!(len > 0.f)) continue;
