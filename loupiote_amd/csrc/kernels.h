@@ -397,12 +397,19 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, f
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
     RayState rs;
-    bool active = false;
+    bool active = false, finished = false;  // finished: traversal over, result still in registers
     uint32_t ray = 0;
     for (;;) {
         const unsigned long long amask = __ballot(active);
         const int n_active = __popcll(amask);
         if (n_active <= refill) {
+            // results are written here, together with the refill, so that the emitter test and the store
+            // run for a batch of lanes instead of once per finishing lane
+            if (finished) {
+                intersect_lights(sc, rs.o, rs.d, rs.best);
+                hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
+                finished = false;
+            }
             puller_pull(pl);
             if (pl.next < pl.end) {
                 const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
@@ -422,9 +429,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, f
             w_node += (uint32_t)__popcll(__ballot(active && rs.tg.y == 0u));
         }
         if (active && ray_step<false, STATS>(sc, rs, stack, n_nodes, n_tris)) {
-            intersect_lights(sc, rs.o, rs.d, rs.best);
-            hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
             active = false;
+            finished = true;
         }
         if (STATS) w_tri += (uint32_t)__popcll(__ballot(n_tris != tris_before));
     }
@@ -448,12 +454,22 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue s
     const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
     RayState rs;
-    bool active = false;
+    bool active = false, finished = false;
     uint32_t ray = 0;
     for (;;) {
         const unsigned long long amask = __ballot(active);
         const int n_active = __popcll(amask);
         if (n_active <= refill) {
+            if (finished) {
+                if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
+                    const uint32_t slot = __float_as_uint(sq.d[ray].w);
+                    const float4 c = sq.c[ray];
+                    float4 L = Lsum[slot];
+                    L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+                    Lsum[slot] = L;
+                }
+                finished = false;
+            }
             puller_pull(pl);
             if (pl.next < pl.end) {
                 const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
@@ -467,14 +483,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue s
             } else if (n_active == 0) break;
         }
         if (active && ray_step<true, STATS>(sc, rs, stack, n_nodes, n_tris)) {
-            if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
-                const uint32_t slot = __float_as_uint(sq.d[ray].w);
-                const float4 c = sq.c[ray];
-                float4 L = Lsum[slot];
-                L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
-                Lsum[slot] = L;
-            }
             active = false;
+            finished = true;
         }
     }
     if (STATS) {
