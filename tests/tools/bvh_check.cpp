@@ -52,6 +52,7 @@ void consider(const Accel &a, uint32_t ti, const float o[3], const float d[3], H
 float safe_inv(float d) { return fabsf(d) > 1.0e-30f ? 1.0f / d : copysignf(1.0e30f, d); }
 
 struct Stats { uint64_t nodes = 0, tris = 0; uint32_t max_stack = 0; };
+bool by_distance = false;  // BVH_CHECK_ORDER=dist: visit inner children nearest first (bound on what ordering can save)
 
 Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
     Hit best;
@@ -96,7 +97,7 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
                 tf = fminf(tf, fmaf(qf, af[k], bf[k]));
             }
             if (!(tn <= tf)) continue;
-            if (is_inner) inner[n_inner++] = {(uint32_t)sl ^ oinv, n.child_base + my_rel};
+            if (is_inner) inner[n_inner++] = {by_distance ? ~__builtin_bit_cast(uint32_t, tn) : ((uint32_t)sl ^ oinv), n.child_base + my_rel};
             else {
                 const uint32_t cnt_bits = meta >> 5, off = meta & 31u;
                 for (uint32_t k = 0; k < 3; ++k)
@@ -124,6 +125,7 @@ int main(int argc, char **argv) {
     std::vector<float> pos((size_t)n * 9);
     if (n && fread(pos.data(), 4, pos.size(), f) != pos.size()) return 2;
     fclose(f);
+    by_distance = getenv("BVH_CHECK_ORDER") && !strcmp(getenv("BVH_CHECK_ORDER"), "dist");
     const int n_rays = atoi(argv[2]);
     const bool brute = atoi(argv[3]) != 0;
 
