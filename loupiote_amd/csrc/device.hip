@@ -66,7 +66,7 @@ struct lpt_renderer {
     uint32_t rank = 0, world = 1, tile_w = 32, tile_h = 8;
     bool use_noise = false, stats = false, timings = false;
     // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
-    int refill = 56;
+    int refill = 44;
     uint32_t trace_waves_per_cu = 32;
     // device memory
     uint32_t n_slots = 0;
