@@ -510,7 +510,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(DScene sc, const 
 // ------------------------------------------------------------------ SPEC §9 textures / environment
 __device__ __forceinline__ int wrap_i(int x, int n) { int m = x % n; return m < 0 ? m + n : m; }
 
-__device__ __forceinline__ float4 texture_lookup(const DScene &sc, uint32_t image, float u, float v, bool srgb) {
+// `lut`: the 256-entry sRGB decode table, staged in LDS by the caller (12 table reads per albedo lookup)
+__device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *lut, uint32_t image, float u, float v, bool srgb) {
     const DImage im = sc.images[image];
     const int W = (int)im.width, H = (int)im.height;
     float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
@@ -527,7 +528,7 @@ __device__ __forceinline__ float4 texture_lookup(const DScene &sc, uint32_t imag
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
         float c00, c10, c01, c11;
-        if (srgb && ch < 3) { c00 = sc.srgb_lut[a00[ch]]; c10 = sc.srgb_lut[a10[ch]]; c01 = sc.srgb_lut[a01[ch]]; c11 = sc.srgb_lut[a11[ch]]; }
+        if (srgb && ch < 3) { c00 = lut[a00[ch]]; c10 = lut[a10[ch]]; c01 = lut[a01[ch]]; c11 = lut[a11[ch]]; }
         else {
             c00 = (float)a00[ch] * 0.003921568859368563f; c10 = (float)a10[ch] * 0.003921568859368563f;
             c01 = (float)a01[ch] * 0.003921568859368563f; c11 = (float)a11[ch] * 0.003921568859368563f;
@@ -624,6 +625,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
                                                   uint32_t seed_base, GBufArgs gb) {
     __shared__ uint32_t lds[8];
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];  // kBlock == 256
+    __syncthreads();
     const uint32_t count = ctr->qcount[bounce];
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounded = (count + 255u) & ~255u;  // keep whole blocks in the loop for the barriers
@@ -692,11 +696,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     float rough = mp.x, metal = mp.y;
                     const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
                     if (atex < sc.n_images) {
-                        const float4 tex = texture_lookup(sc, atex, tu, tvv, true);
+                        const float4 tex = texture_lookup(sc, s_lut, atex, tu, tvv, true);
                         base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
                     }
                     if (mtex < sc.n_images) {
-                        const float4 tex = texture_lookup(sc, mtex, tu, tvv, false);
+                        const float4 tex = texture_lookup(sc, s_lut, mtex, tu, tvv, false);
                         rough *= tex.y; metal *= tex.z;
                     }
                     g_n = Ns; g_P = P;
