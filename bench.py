@@ -175,10 +175,11 @@ def main():
     elapsed = float(tl.item())
     closest, shadow, shaded = [float(x) for x in rays.tolist()]
 
-    # ---- roofline of the dominant kernel (k_intersect), rank 0: algorithmic bytes per launch
-    # = rays/launch * (32 B ray read + 16 B hit write + N*64 B nodes + T*48 B triangles), with N, T
-    # (mean nodes visited / triangles tested per closest-hit ray) measured by the stats variant of
-    # the same kernel on the same frames, outside the timed region.
+    # ---- roofline of the dominant kernel (k_trace), rank 0: algorithmic bytes per launch
+    # = closest rays * (32 B ray read + 16 B hit write + N*80 B nodes + T*48 B triangles)
+    # + shadow rays * (32 B ray read + 4 B + Ns*80 B + Ts*48 B), with N, T, Ns, Ts (mean nodes visited /
+    # triangles tested per ray) measured by the stats variant of the same kernel on the same frames,
+    # outside the timed region.
     r = rs[0]
     step_no[0] = 0
     r.enable_stats(True)
@@ -192,11 +193,20 @@ def main():
     ns_bar = st.shadow_nodes / max(st.shadow, 1)
     ts_bar = st.shadow_tris / max(st.shadow, 1)
     accel = sg.stats()
+    # dominant kernel: k_trace (closest-hit rays of bounce b+1 and shadow rays of bounce b in one persistent launch;
+    # stages "intersection" = launches that carry closest-hit rays, "shadow" = the last, shadow-only launch)
     b_ray = 32.0 + 16.0 + n_bar * accel.node_bytes + t_bar * accel.tri_bytes
-    i_ms, i_launches = timings["intersection"]
-    rays_per_launch = counts.closest / max(i_launches, 1)
-    avg_ms = i_ms / max(i_launches, 1)
-    achieved = (rays_per_launch * b_ray) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    b_sh = 32.0 + 4.0 + ns_bar * accel.node_bytes + ts_bar * accel.tri_bytes
+
+    def trace_stage(tm, cl, sh):
+        ms = tm.get("intersection", (0.0, 0))[0] + tm.get("shadow", (0.0, 0))[0]
+        launches = tm.get("intersection", (0.0, 0))[1] + tm.get("shadow", (0.0, 0))[1]
+        avg = ms / max(launches, 1)
+        byts = (cl * b_ray + sh * b_sh) / max(launches, 1)
+        return avg, launches, byts, (byts / (avg * 1e-3) / 1e9 if avg > 0 else 0.0)
+
+    avg_ms, i_launches, bytes_per_launch, achieved = trace_stage(timings, counts.closest, counts.shadow)
+    rays_per_launch = (counts.closest + counts.shadow) / max(i_launches, 1)
     # the same kernel with nothing co-running (one extra untimed step on renderer 0): with --pipeline 2 the
     # kernels of two frames share the chip, which lengthens each launch although the step gets shorter
     r.reset_ray_counts()
@@ -204,16 +214,15 @@ def main():
     step_no[0] = 0
     step()
     fence()
-    s_ms, s_launches = r.timings()["intersection"]
+    solo_t = r.timings()
     r.enable_timings(False)
-    s_rays = r.ray_counts().closest / max(s_launches, 1)
-    s_avg = s_ms / max(s_launches, 1)
-    solo = (s_rays * b_ray) / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
+    sc_ = r.ray_counts()
+    s_avg, s_launches, _, solo = trace_stage(solo_t, sc_.closest, sc_.shadow)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_intersect_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("k_trace_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -236,11 +245,11 @@ def main():
                        "tiles": "32x8 interleaved, tile_id mod N", "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
             "ms_per_frame": elapsed / args.steps * 1e3,
-            "roofline": {"bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": i_launches, "frames_in_flight": P,
                          "solo": {"achieved": solo, "frac": solo / HBM_PEAK_GBS, "avg_launch_ms": s_avg, "launches": s_launches}, "rays_per_launch": rays_per_launch,
-                         "bytes_per_ray": b_ray, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
+                         "bytes_per_launch": bytes_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},

@@ -67,6 +67,7 @@ struct lpt_renderer {
     bool use_noise = false, stats = false, timings = false;
     // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
     int refill = 44;
+    bool merge_trace = true;
     uint32_t trace_waves_per_cu = 32;
     // device memory
     uint32_t n_slots = 0;
@@ -431,6 +432,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
         hipError_t se = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     }
+    if (const char *ev = getenv("LPT_MERGE_TRACE")) r->merge_trace = atoi(ev) != 0;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
@@ -709,23 +711,40 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         stage_end(r);
 
         uint32_t seed = r->seed;
+        // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
+        // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
+        // instead of 2*nb; split (LPT_MERGE_TRACE=0): IntersectorPass and the shadow pass as separate launches.
+        auto trace = [&](int cb, int sb) {
+            stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW);  // :457-464, :493-498
+            const Queue qin = r->q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
+            if (r->stats) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->sq, r->Lsum, r->ctr, cb, sb, r->refill);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->sq, r->Lsum, r->ctr, cb, sb, r->refill);
+            stage_end(r);
+        };
+        if (r->merge_trace) trace(0, -1);
         for (uint32_t b = 0; b < nb; ++b) {
             seed += 1u;                          // :453, :487
             const Queue qin = r->q[b & 1u], qout = r->q[(b + 1u) & 1u];
-            stage_begin(r, ST_INTERSECT);        // :457-464, :493-498
-            if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
-            else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
-            stage_end(r);
+            if (!r->merge_trace) {
+                stage_begin(r, ST_INTERSECT);    // :457-464, :493-498
+                if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
+                else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
+                stage_end(r);
+            }
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
                 hipLaunchKernelGGL(k_shade<true>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
             else
                 hipLaunchKernelGGL(k_shade<false>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
             stage_end(r);
-            stage_begin(r, ST_SHADOW);
-            if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
-            stage_end(r);
+            if (r->merge_trace) {
+                trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);
+            } else {
+                stage_begin(r, ST_SHADOW);
+                if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
+                stage_end(r);
+            }
         }
         if (r->mode == LPT_BLIT_PATHTRACE) {
             // AccumulationPass (:523-538)

@@ -237,8 +237,8 @@ __device__ __forceinline__ void ray_begin(RayState &rs, f3 o, f3 d, float tmax) 
 }
 
 // returns true when the ray is finished (ANY: also as soon as something is hit; best.prim != ~0 then)
-template <bool ANY, bool STATS>
-__device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *stack, uint32_t &n_nodes, uint32_t &n_tris) {
+template <bool STATS>
+__device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris) {
     if (rs.tg.y == 0u) {
         if (!(rs.ng.y & 0xFF000000u)) {
             if (rs.sp == 0) return true;
@@ -317,6 +317,11 @@ __device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *
         }
     }
     return false;
+}
+
+template <bool ANY, bool STATS>
+__device__ __forceinline__ bool ray_step(const DScene &sc, RayState &rs, uint2 *stack, uint32_t &n_nodes, uint32_t &n_tris) {
+    return ray_step_any<STATS>(sc, rs, stack, ANY, n_nodes, n_tris);
 }
 
 // one ray start to finish (stand-alone queries)
@@ -490,6 +495,95 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue s
     if (STATS) {
         atomicAdd(&ctr->shadow_nodes, (unsigned long long)n_nodes);
         atomicAdd(&ctr->shadow_tris, (unsigned long long)n_tris);
+    }
+}
+
+// Closest-hit rays of bounce `cb` and shadow rays of bounce `sb` in ONE persistent launch (either may be
+// absent: -1).  Both queues were filled by the same shading pass; tracing them together halves the number of
+// traversal launches per frame and lets the short shadow rays fill the lanes that the tail of the closest-hit
+// queue leaves idle.  A wave drains closest-hit chunks first, then shadow chunks; a lane remembers which kind
+// of ray it carries.  Results are identical to k_intersect followed by k_shadow: the only shared state is
+// Lsum, which only the shadow part touches.
+template <bool STATS>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
+                                                       int cb, int sb, int refill) {
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
+    ChunkPuller pc, ps;
+    puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : ctr->qcount[cb]);
+    puller_init(ps, &ctr->shead[(sb < 0 ? 0 : sb) * 8 * 32], sb < 0 ? 0u : ctr->shcount[sb]);
+    if (cb < 0) pc.dry = true;
+    if (sb < 0) ps.dry = true;
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
+    uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
+    RayState rs;
+    bool active = false, finished = false, shadow = false;
+    uint32_t ray = 0;
+    for (;;) {
+        const unsigned long long amask = __ballot(active);
+        const int n_active = __popcll(amask);
+        if (n_active <= refill) {
+            // results are written here, together with the refill, so that the emitter test / the deposit and
+            // the stores run for a batch of lanes instead of once per finishing lane
+            if (finished) {
+                if (shadow) {
+                    if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
+                        const uint32_t slot = __float_as_uint(sq.d[ray].w);
+                        const float4 c = sq.c[ray];
+                        float4 L = Lsum[slot];
+                        L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+                        Lsum[slot] = L;
+                    }
+                } else {
+                    intersect_lights(sc, rs.o, rs.d, rs.best);
+                    hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
+                }
+                finished = false;
+            }
+            puller_pull(pc);
+            const bool use_s = !(pc.next < pc.end);  // wave-uniform
+            if (use_s) puller_pull(ps);
+            const uint32_t nx = use_s ? ps.next : pc.next, en = use_s ? ps.end : pc.end;
+            if (nx < en) {
+                const uint32_t idx = nx + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
+                if (!active && idx < en) {
+                    float4 o4, d4;
+                    if (use_s) { o4 = sq.o[idx]; d4 = sq.d[idx]; } else { o4 = q.o[idx]; d4 = q.d[idx]; }
+                    ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), use_s ? o4.w : LPT_T_INF);
+                    ray = idx;
+                    shadow = use_s;
+                    active = true;
+                }
+                const uint32_t adv = min(en, nx + (uint32_t)(64 - n_active));
+                if (use_s) ps.next = adv; else pc.next = adv;
+            } else if (n_active == 0) break;
+        }
+        uint32_t dn = 0, dt = 0;
+        if (STATS) {
+            w_steps++;
+            w_live += (uint32_t)__popcll(__ballot(active));
+            w_node += (uint32_t)__popcll(__ballot(active && rs.tg.y == 0u));
+        }
+        if (active && ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt)) {
+            active = false;
+            finished = true;
+        }
+        if (STATS) {
+            w_tri += (uint32_t)__popcll(__ballot(dt != 0u));
+            if (shadow) { s_nodes += dn; s_tris += dt; } else { n_nodes += dn; n_tris += dt; }
+        }
+    }
+    if (STATS) {
+        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
+        atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
+        if (lane == 0) {
+            atomicAdd(&ctr->wave_steps, (unsigned long long)w_steps);
+            atomicAdd(&ctr->live_lanes, (unsigned long long)w_live);
+            atomicAdd(&ctr->node_lanes, (unsigned long long)w_node);
+            atomicAdd(&ctr->tri_lanes, (unsigned long long)w_tri);
+        }
     }
 }
 
