@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, reduce) even with one rank")
+    ap.add_argument("--exchange", choices=["reduce", "gather"], default="reduce",
+                    help="frame exchange for N>1: dense RCCL reduce of the accumulation buffer (north star) or a gather of owned tiles only")
     ap.add_argument("--pipeline", type=int, default=2, help="renderers (each with its own HIP stream) that take consecutive steps in turn")
     ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
@@ -115,6 +117,10 @@ def main():
         ptr, nbytes = rr.radiance_device_ptr()
         accums.append(torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank)))
         frames.append(torch.empty_like(accums[-1]) if use_dist else None)
+    gathers = None
+    if use_dist and args.exchange == "gather":
+        from loupiote_amd.dist import OwnedTileGather
+        gathers = [OwnedTileGather(WIDTH, HEIGHT, rank, world, device=torch.device("cuda", local_rank)) for _ in range(P)]
     r = rs[0]
     step_no = [0]
 
@@ -133,8 +139,11 @@ def main():
             # radiance reduce over xGMI: ordered after this renderer's stream, which its next
             # frame's kernels in turn wait on (torch issues the RCCL op relative to the stream)
             with torch.cuda.stream(exts[k]):
-                frames[k].copy_(accums[k], non_blocking=True)
-                dist.reduce(frames[k], dst=0, op=dist.ReduceOp.SUM)
+                if gathers is not None:
+                    gathers[k](accums[k].view(HEIGHT, WIDTH, 4))   # owned pixels only (W*H/N * 16 B per rank)
+                else:
+                    frames[k].copy_(accums[k], non_blocking=True)
+                    dist.reduce(frames[k], dst=0, op=dist.ReduceOp.SUM)
 
     def fence():
         if use_dist:
@@ -242,7 +251,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in, 262144 tris], 1920x1080, 4 spp, depth 8, "
                                    "camera (-10,1,0)->(1,0.35,0); step = 1 frame (raytrace_n(view,4) == 4 x raytrace, + reduce)",
-                       "tiles": "32x8 interleaved, tile_id mod N", "rays_per_step": (closest + shadow) / args.steps,
+                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": args.exchange if use_dist else "none", "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
             "ms_per_frame": elapsed / args.steps * 1e3,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -42,7 +42,11 @@ def _worker(rank, world, port, out_path):
     mask = D.owned_mask(W, H, rank, world)
     assert np.array_equal(acc[..., 3] > 0, mask)
     buf = torch.from_numpy(acc.copy())
+    buf2 = torch.from_numpy(acc.copy())
     D.reduce_radiance(buf, dst=0)                       # the one data-path collective
+    D.OwnedTileGather(W, H, rank, world)(buf2)          # its compact form: owned pixels only
+    if rank == 0:
+        assert buf2.numpy().tobytes() == buf.numpy().tobytes()
     rays = torch.tensor([cnt.closest + cnt.shadow], dtype=torch.float64)
     dist.all_reduce(rays, op=dist.ReduceOp.SUM)         # whole-job ray count
     t = torch.tensor([0.5 + rank], dtype=torch.float64)
@@ -59,6 +63,34 @@ def _worker(rank, world, port, out_path):
 def test_two_rank_tile_sharded_reduce_equals_single_rank(tmp_path):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
+
+
+def _worker_exchange(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from loupiote_amd import dist as D
+    ok = True
+    for (W, H) in [(100, 37), (64, 16), (33, 9)]:       # ragged tiles, uneven tile counts per rank
+        rng = np.random.default_rng(100 * W + rank)
+        a = rng.random((H, W, 4), dtype=np.float32)
+        a[~D.owned_mask(W, H, rank, world)] = 0.0
+        r1, r2 = torch.from_numpy(a.copy()), torch.from_numpy(a.copy())
+        D.reduce_radiance(r1, dst=0)
+        D.OwnedTileGather(W, H, rank, world)(r2)
+        if rank == 0:
+            ok = ok and r1.numpy().tobytes() == r2.numpy().tobytes() and bool((r1[..., 3] > 0).all())
+    if rank == 0:
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owned_tile_gather_equals_reduce_three_ranks(tmp_path):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker_exchange, args=(3, _free_port(), str(out)), nprocs=3, join=True)
     assert out.read_text() == "ok"
 
 
