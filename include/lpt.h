@@ -240,6 +240,12 @@ int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32
  * caller.  LPT_ERR_ACCEL_BUILD when the build fails. */
 int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out);
 int lpt_scene_gpu_destroy(lpt_scene_gpu *sg);
+/* replaces: Instance::set_transform + a new SceneGPU (crates/standalone/src/lib.rs:118-121, scene.rs:151):
+ * after lpt_scene_set_instance_transform on the CPU scene, re-bakes only the changed instances and refits the
+ * wide BVH on the GPU (topology kept).  The meshes and the instance list must be the uploaded ones
+ * (LPT_ERR_INVALID_ARG otherwise: upload again).  Renderers bound to this lpt_scene_gpu keep working; call
+ * lpt_renderer_reset_accumulation as after any scene change.  out_rebaked may be NULL. */
+int lpt_scene_gpu_update_instances(lpt_scene_gpu *scene_gpu, const lpt_scene *scene, uint32_t *out_rebaked);
 int lpt_scene_gpu_stats(const lpt_scene_gpu *sg, lpt_accel_stats *out);
 
 /* replaces: ProbeGPU::new(device, queue, data, width, height)

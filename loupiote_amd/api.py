@@ -205,6 +205,13 @@ class SceneGPU:
         _check(A.lib().lpt_scene_gpu_stats(self._h, C.byref(s)))
         return s
 
+    def update_instances(self, scene):
+        """after `scene.set_instance_transform(...)` (standalone/src/lib.rs:118-121): re-bake the changed instances
+        and refit the wide BVH on the GPU; returns how many instances were re-baked"""
+        n = C.c_uint32(0)
+        _check(A.lib().lpt_scene_gpu_update_instances(self._h, scene._h, C.byref(n)))
+        return int(n.value)
+
     def trace_closest(self, origins, dirs):
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(dirs, np.float32)

@@ -154,43 +154,53 @@ inline void normalize3(float v[3]) {
     v[0] *= inv; v[1] *= inv; v[2] *= inv;
 }
 
+// SPEC §2.5: one instance -> world-space triangles (appended to `verts`, 3 per triangle); returns the material
+uint32_t bake_one(const lpt_scene &s, size_t ii, std::vector<lpt_vertex> &verts) {
+    const lpt_instance &inst = s.instances[ii];
+    uint32_t mi = inst.material_index;
+    if (mi >= s.materials.size()) mi = 0;
+    if (inst.blas_index >= s.entries.size()) return mi;
+    const lpt_blas_entry &e = s.entries[inst.blas_index];
+    const uint32_t ntri = e.index_count / 3u;
+    const float *m = inst.model_to_world;
+    const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
+    const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const float c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
+    const float c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
+    for (uint32_t t = 0; t < ntri; ++t) {
+        for (int k = 0; k < 3; ++k) {
+            const lpt_vertex &v = s.vertices[e.vertex_offset + s.indices[e.index_offset + 3 * t + k]];
+            const float x = v.position[0], y = v.position[1], z = v.position[2];
+            lpt_vertex o;
+            o.position[0] = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+            o.position[1] = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+            o.position[2] = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+            o.position[3] = v.position[3];
+            const float nx = v.normal[0], ny = v.normal[1], nz = v.normal[2];
+            float n[3] = {(c00 * nx + c01 * ny) + c02 * nz, (c10 * nx + c11 * ny) + c12 * nz, (c20 * nx + c21 * ny) + c22 * nz};
+            normalize3(n);
+            o.normal[0] = n[0]; o.normal[1] = n[1]; o.normal[2] = n[2]; o.normal[3] = v.normal[3];
+            verts.push_back(o);
+        }
+    }
+    return mi;
+}
+
 // SPEC §2.5: instances -> world-space soup
 void bake(const lpt_scene &s, Accel &out) {
     out.tri_verts.clear();
     out.tri_material.clear();
+    out.inst_first.assign(s.instances.size(), 0u);
+    out.inst_count.assign(s.instances.size(), 0u);
     for (size_t ii = 0; ii < s.instances.size(); ++ii) {
-        const lpt_instance &inst = s.instances[ii];
-        if (inst.blas_index >= s.entries.size()) continue;
-        const lpt_blas_entry &e = s.entries[inst.blas_index];
-        const uint32_t ntri = e.index_count / 3u;
-        if (!ntri) continue;
-        const float *m = inst.model_to_world;
-        const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
-        const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
-        const float c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
-        const float c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
-        uint32_t mi = inst.material_index;
-        if (mi >= s.materials.size()) mi = 0;
-        for (uint32_t t = 0; t < ntri; ++t) {
-            for (int k = 0; k < 3; ++k) {
-                const lpt_vertex &v = s.vertices[e.vertex_offset + s.indices[e.index_offset + 3 * t + k]];
-                const float x = v.position[0], y = v.position[1], z = v.position[2];
-                lpt_vertex o;
-                o.position[0] = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
-                o.position[1] = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
-                o.position[2] = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
-                o.position[3] = v.position[3];
-                const float nx = v.normal[0], ny = v.normal[1], nz = v.normal[2];
-                float n[3] = {(c00 * nx + c01 * ny) + c02 * nz, (c10 * nx + c11 * ny) + c12 * nz, (c20 * nx + c21 * ny) + c22 * nz};
-                normalize3(n);
-                o.normal[0] = n[0]; o.normal[1] = n[1]; o.normal[2] = n[2]; o.normal[3] = v.normal[3];
-                out.tri_verts.push_back(o);
-            }
-            out.tri_material.push_back(mi);
-        }
+        const size_t before = out.tri_verts.size() / 3;
+        const uint32_t mi = bake_one(s, ii, out.tri_verts);
+        const size_t ntri = out.tri_verts.size() / 3 - before;
+        out.inst_first[ii] = (uint32_t)before;
+        out.inst_count[ii] = (uint32_t)ntri;
+        out.tri_material.insert(out.tri_material.end(), ntri, mi);
     }
 }
-
 
 // SAH-optimal collapse of the binary tree into 8-wide nodes (Ylitie, Karras & Laine 2017, §4.1).
 // C(n,i) = cheapest way to represent the subtree of binary node n by at most i roots, a root being
@@ -266,6 +276,14 @@ Box padded_box(const lpt_vertex *v) {
 
 }  // namespace
 
+void bake_instance(const lpt_scene &scene, size_t instance, std::vector<lpt_vertex> &verts, std::vector<WoopTri> &woop) {
+    verts.clear();
+    woop.clear();
+    bake_one(scene, instance, verts);
+    woop.resize(verts.size() / 3);
+    for (size_t t = 0; t < woop.size(); ++t) woop_from_triangle(verts[3 * t].position, verts[3 * t + 1].position, verts[3 * t + 2].position, woop[t]);
+}
+
 int bake_and_build(const lpt_scene &scene, Accel &out) {
     const auto t0 = std::chrono::steady_clock::now();
     bake(scene, out);
@@ -292,6 +310,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         out.woop.push_back(z);
         out.leaf_prim.push_back(LPT_INVALID_INDEX);
         out.max_depth = 1;
+        out.level_start = {0u, 1u};
         return LPT_OK;
     }
     Builder b;
@@ -320,10 +339,12 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     out.woop.reserve(n);
     out.leaf_prim.reserve(n);
     uint32_t max_depth = 1;
+    out.level_start.clear();
     for (size_t w = 0; w < queue.size(); ++w) {
         const int32_t root = queue[w].bvh2;
         const uint32_t depth = queue[w].depth;
         max_depth = std::max(max_depth, depth);
+        if (out.level_start.size() < depth) out.level_start.push_back((uint32_t)w);  // breadth first: depths are non-decreasing
         Kid kids[8];
         int nk = 0;
         if (collapse) {
@@ -448,6 +469,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         fprintf(stderr, "\n");
     }
     out.max_depth = max_depth;
+    out.level_start.push_back((uint32_t)out.nodes.size());
     if (out.woop.size() != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %zu of %u triangles referenced", out.woop.size(), n);
     out.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return LPT_OK;

@@ -61,10 +61,15 @@ struct Accel {
     std::vector<uint32_t> leaf_prim;     // leaf slot -> baked triangle id
     uint32_t max_depth = 0;
     float build_ms = 0.f;
+    // bookkeeping for refits (lpt_scene_gpu_update_instances)
+    std::vector<uint32_t> inst_first, inst_count;  // per scene instance: its run of baked triangles
+    std::vector<uint32_t> level_start;             // nodes are stored breadth first: level l = [level_start[l], level_start[l+1])
 };
 
 // bvh.cpp
 int bake_and_build(const lpt_scene &scene, Accel &out);
+// world-space vertices (3 per triangle) and Woop maps of ONE instance, exactly as bake_and_build produces them
+void bake_instance(const lpt_scene &scene, size_t instance, std::vector<lpt_vertex> &verts, std::vector<WoopTri> &woop);
 void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3], WoopTri &w);
 
 // png.cpp

@@ -36,6 +36,11 @@ struct lpt_scene_gpu {
     void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr, *tri_material = nullptr;
     void *materials = nullptr, *lights = nullptr, *texels = nullptr, *images = nullptr, *srgb_lut = nullptr;
     lpt_accel_stats stats{};
+    // refit bookkeeping (lpt_scene_gpu_update_instances)
+    void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
+    std::vector<uint32_t> inst_first, inst_count, level_start;
+    std::vector<lpt_instance> instances;                                // as baked
+    size_t n_entries = 0, n_vertices = 0, n_indices = 0;
 };
 
 struct lpt_probe {
@@ -172,7 +177,8 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     if (!sg) return LPT_OK;
     hipSetDevice(sg->dev->ordinal);
     hipStreamSynchronize(sg->dev->stream);
-    void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->tri_material, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut};
+    void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->tri_material, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
+                    sg->tri_slot, sg->node_lo, sg->node_hi};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
     return LPT_OK;
@@ -216,7 +222,17 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
         lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
     }
     UP(srgb_lut, lut)
+    std::vector<uint32_t> tri_slot(acc.leaf_prim.size(), 0u);
+    if (!acc.tri_material.empty())
+        for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
+    UP(tri_slot, tri_slot)
+    std::vector<float4> boxes(acc.nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));  // filled by the first refit
+    UP(node_lo, boxes)
+    UP(node_hi, boxes)
 #undef UP
+    sg->inst_first = acc.inst_first; sg->inst_count = acc.inst_count; sg->level_start = acc.level_start;
+    sg->instances = scene->instances;
+    sg->n_entries = scene->entries.size(); sg->n_vertices = scene->vertices.size(); sg->n_indices = scene->indices.size();
     hipError_t e = hipStreamSynchronize(s);  // host vectors die at scope exit
     if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
     DScene &d = sg->d;
@@ -250,6 +266,60 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
 int lpt_scene_gpu_stats(const lpt_scene_gpu *sg, lpt_accel_stats *out) {
     if (!sg || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_stats: null");
     *out = sg->stats;
+    return LPT_OK;
+}
+
+// Interactive edit (reference: Instance::set_transform, crates/standalone/src/lib.rs:118-121, followed by a new
+// SceneGPU): re-bake the instances whose transform / material changed, upload their triangles and REFIT the wide
+// BVH on the GPU (topology kept, all boxes recomputed level by level).  The scene's meshes and instance list
+// must be the ones that were uploaded; anything else needs lpt_scene_upload again.
+int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, uint32_t *out_rebaked) {
+    if (!sg || !scene) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: null");
+    if (scene->instances.size() != sg->instances.size() || scene->entries.size() != sg->n_entries ||
+        scene->vertices.size() != sg->n_vertices || scene->indices.size() != sg->n_indices)
+        return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: the scene's meshes / instance list changed since the upload; upload again");
+    HIP_TRY(hipSetDevice(sg->dev->ordinal));
+    hipStream_t s = sg->dev->stream;
+    uint32_t changed = 0;
+    std::vector<lpt_vertex> verts;
+    std::vector<WoopTri> woop;
+    for (size_t i = 0; i < scene->instances.size(); ++i) {
+        const lpt_instance &now = scene->instances[i];
+        lpt_instance &was = sg->instances[i];
+        if (now.blas_index != was.blas_index)
+            return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: instance %zu refers to another mesh; upload again", i);
+        if (memcmp(&now, &was, sizeof now) == 0) continue;
+        bake_instance(*scene, i, verts, woop);
+        if (verts.size() / 3 != sg->inst_count[i]) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: triangle count of instance %zu changed", i);
+        const uint32_t first = sg->inst_first[i], n = sg->inst_count[i];
+        for (size_t k = 0; k < verts.size(); ++k)
+            for (int a = 0; a < 3; ++a)
+                if (!std::isfinite(verts[k].position[a])) return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in re-baked instance %zu", i);
+        if (n) {
+            HIP_TRY(hipMemcpyAsync((lpt_vertex *)sg->tri_verts + 3u * (size_t)first, verts.data(), sizeof(lpt_vertex) * verts.size(), hipMemcpyHostToDevice, s));
+            void *tmp = nullptr;
+            HIP_TRY(hipMalloc(&tmp, sizeof(WoopTri) * n));
+            HIP_TRY(hipMemcpyAsync(tmp, woop.data(), sizeof(WoopTri) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_scatter_woop, dim3(div_up(n, 256u)), dim3(256), 0, s, (const float4 *)tmp, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, first, n);
+            uint32_t mi = now.material_index;
+            if (mi >= scene->materials.size()) mi = 0;
+            std::vector<uint32_t> mats(n, mi);
+            HIP_TRY(hipMemcpyAsync((uint32_t *)sg->tri_material + first, mats.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));  // host staging vectors are reused by the next instance
+            hipFree(tmp);
+        }
+        was = now;
+        ++changed;
+    }
+    if (changed && sg->stats.triangles) {
+        for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
+            const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
+            if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (out_rebaked) *out_rebaked = changed;
     return LPT_OK;
 }
 

@@ -1059,4 +1059,92 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_occluded(DScene sc, const
     out[i] = traverse<true, false>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, stack, h, a, b) ? 1 : 0;
 }
 
+
+// ------------------------------------------------------------------ refit (lpt_scene_gpu_update_instances)
+// The tree keeps its topology; every node's child boxes, grid origin and exponents are recomputed from the
+// (moved) triangles, one breadth-first level per launch, deepest level first.  Mirrors the quantisation of
+// the host builder (bvh.cpp): padded triangle boxes, power-of-two grid step >= extent/255, floor / ceil.
+__device__ __forceinline__ void refit_grow_tri(const DScene &sc, uint32_t prim, float lo[3], float hi[3]) {
+    const float4 *tv = sc.tri_verts + 6u * (size_t)prim;
+    const float4 P0 = tv[0], P1 = tv[2], P2 = tv[4];
+    const float px[3] = {P0.x, P1.x, P2.x}, py[3] = {P0.y, P1.y, P2.y}, pz[3] = {P0.z, P1.z, P2.z};
+    const float *pp[3] = {px, py, pz};
+    for (int a = 0; a < 3; ++a) {
+        float l = fminf(fminf(pp[a][0], pp[a][1]), pp[a][2]), h = fmaxf(fmaxf(pp[a][0], pp[a][1]), pp[a][2]);
+        const float m = fmaxf(fabsf(l), fabsf(h));
+        const float e = 4e-6f * m + 1e-6f * (h - l) + 1e-30f;   // bvh.cpp padded_box
+        l -= e; h += e;
+        lo[a] = fminf(lo[a], l); hi[a] = fmaxf(hi[a], h);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, float4 *node_lo, float4 *node_hi, uint32_t first, uint32_t last) {
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last) return;
+    uint4 *nw = nodes_rw + 5u * (size_t)i;
+    const uint4 n0 = nw[0], n1 = nw[1];
+    const uint32_t imask = n0.w >> 24;
+    float clo[8][3], chi[8][3];
+    float nlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, nhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t rel = 0;
+    bool any = false;
+    for (int sl = 0; sl < 8; ++sl) {
+        const uint32_t meta = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xFFu;
+        for (int a = 0; a < 3; ++a) { clo[sl][a] = 3.0e38f; chi[sl][a] = -3.0e38f; }
+        if ((imask >> sl) & 1u) {
+            const uint32_t c = n1.x + rel++;
+            const float4 l = node_lo[c], h = node_hi[c];
+            clo[sl][0] = l.x; clo[sl][1] = l.y; clo[sl][2] = l.z; chi[sl][0] = h.x; chi[sl][1] = h.y; chi[sl][2] = h.z;
+        } else if (meta) {
+            const uint32_t bits = meta >> 5, off = meta & 31u;
+            for (uint32_t k = 0; k < 3; ++k)
+                if ((bits >> k) & 1u) refit_grow_tri(sc, sc.leaf_prim[n1.y + off + k], clo[sl], chi[sl]);
+        } else continue;
+        any = true;
+        for (int a = 0; a < 3; ++a) { nlo[a] = fminf(nlo[a], clo[sl][a]); nhi[a] = fmaxf(nhi[a], chi[sl][a]); }
+    }
+    if (!any) return;  // the empty scene's single node
+    node_lo[i] = make_float4(nlo[0], nlo[1], nlo[2], 0.f);
+    node_hi[i] = make_float4(nhi[0], nhi[1], nhi[2], 0.f);
+    uint32_t eb[3];
+    double scale[3];
+    for (int a = 0; a < 3; ++a) {
+        const double ext = (double)nhi[a] - (double)nlo[a];
+        int e = -126;
+        if (ext > 0.0) {
+            int k;
+            frexp(ext / 255.0, &k);
+            e = min(max(k, -126), 127);
+        }
+        eb[a] = (uint32_t)(e + 127);
+        scale[a] = ldexp(1.0, e);
+    }
+    uint8_t q[6][8];
+    for (int sl = 0; sl < 8; ++sl) {
+        const uint32_t meta = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xFFu;
+        if (!meta) { for (int a = 0; a < 3; ++a) { q[a][sl] = 255; q[3 + a][sl] = 0; } continue; }
+        for (int a = 0; a < 3; ++a) {
+            const double l = floor(((double)clo[sl][a] - (double)nlo[a]) / scale[a]);
+            const double h = ceil(((double)chi[sl][a] - (double)nlo[a]) / scale[a]);
+            q[a][sl] = (uint8_t)fmin(fmax(l, 0.0), 255.0);
+            q[3 + a][sl] = (uint8_t)fmin(fmax(h, 0.0), 255.0);
+        }
+    }
+    auto pack4 = [&](int plane, int h) { return (uint32_t)q[plane][4 * h] | ((uint32_t)q[plane][4 * h + 1] << 8) | ((uint32_t)q[plane][4 * h + 2] << 16) | ((uint32_t)q[plane][4 * h + 3] << 24); };
+    nw[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24));
+    nw[2] = make_uint4(pack4(0, 0), pack4(0, 1), pack4(1, 0), pack4(1, 1));
+    nw[3] = make_uint4(pack4(2, 0), pack4(2, 1), pack4(3, 0), pack4(3, 1));
+    nw[4] = make_uint4(pack4(4, 0), pack4(4, 1), pack4(5, 0), pack4(5, 1));
+}
+
+// new Woop maps of a re-baked instance go to the leaf slots of its triangles
+__global__ __launch_bounds__(256) void k_scatter_woop(const float4 *src, float4 *woop, const uint32_t *tri_slot, uint32_t first_prim, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = tri_slot[first_prim + i];
+    woop[3u * (size_t)slot] = src[3u * (size_t)i];
+    woop[3u * (size_t)slot + 1] = src[3u * (size_t)i + 1];
+    woop[3u * (size_t)slot + 2] = src[3u * (size_t)i + 2];
+}
+
 }  // namespace lptd
