@@ -143,6 +143,9 @@ class Renderer {  // renderer.rs:169-811
     void set_vfov(float radians) { check(lpt_renderer_set_vfov(h_, radians)); }
     void set_shard(uint32_t rank, uint32_t world, uint32_t tile_w = 32, uint32_t tile_h = 8) { check(lpt_renderer_set_shard(h_, rank, world, tile_w, tile_h)); }
     lpt_ray_counts ray_counts() { lpt_ray_counts c; check(lpt_renderer_get_ray_counts(h_, &c)); return c; }
+    /// multi-GPU denoising: this rank's filter inputs (device pointers) and, on rank 0 after the exchange, the filter passes
+    void denoiser_inputs(void **noisy, void **gbuffer, void **motion, size_t *n_pixels) { check(lpt_renderer_denoiser_inputs(h_, noisy, gbuffer, motion, n_pixels)); }
+    void denoise_filter() { check(lpt_renderer_denoise_filter(h_)); }
     lpt_renderer *handle() const { return h_; }
 
    private:

@@ -338,6 +338,14 @@ int lpt_renderer_set_vfov(lpt_renderer *r, float radians);
  * ≡ rank (mod world_size).  Default (0,1,32,8) = everything. */
 int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world_size, uint32_t tile_w,
                            uint32_t tile_h);
+/* new (multi-GPU denoising; reference: asvgf passes run on the one GPU, renderer.rs:513-522).  With set_shard(world > 1)
+ * and a denoising BlitMode, raytrace() fills only this rank's tiles of the filter inputs.  `lpt_renderer_denoiser_inputs`
+ * returns the device pointers of the full-frame input buffers of the CURRENT frame (noisy radiance float4, G-buffer
+ * uint4, motion float2; n_pixels each; zero outside the rank's tiles) so that the host can sum them onto rank 0 (RCCL
+ * reduce; integer sum for the G-buffer).  `lpt_renderer_denoise_filter` then runs temporal accumulation, the a-trous
+ * iterations and the composite over the whole frame on that rank (no-op for world == 1: raytrace() already did). */
+int lpt_renderer_denoiser_inputs(lpt_renderer *r, void **noisy, void **gbuffer, void **motion, size_t *n_pixels);
+int lpt_renderer_denoise_filter(lpt_renderer *r);
 /* Device address + byte size of the fp32 RGBA accumulation buffer
  * (rgb = radiance SUM, a = sample count; zero where not owned).  The collective
  * layer sums it across ranks (RCCL reduce) before read_radiance on rank 0. */

@@ -120,6 +120,8 @@ SIGNATURES = {
     "lpt_renderer_set_vfov": (_i, [_vp, _f]),
     "lpt_renderer_set_shard": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "lpt_renderer_radiance_device_ptr": (_i, [_vp, _pvp, C.POINTER(_sz)]),
+    "lpt_renderer_denoiser_inputs": (_i, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "lpt_renderer_denoise_filter": (_i, [_vp]),
     "lpt_renderer_get_ray_counts": (_i, [_vp, C.POINTER(RayCounts)]),
     "lpt_renderer_reset_ray_counts": (_i, [_vp]),
     "lpt_renderer_enable_stats": (_i, [_vp, _i]),

@@ -346,6 +346,17 @@ class Renderer:
         _check(A.lib().lpt_renderer_read_denoiser(self._h, A.ptr(g), A.ptr(m), A.ptr(rad), A.ptr(hist)))
         return g, m, rad, hist
 
+    def denoiser_inputs(self):
+        """device pointers of this frame's filter inputs for the multi-GPU exchange:
+        (noisy float4*, gbuffer uint4*, motion float2*, n_pixels)"""
+        n, g, m, c = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _check(A.lib().lpt_renderer_denoiser_inputs(self._h, C.byref(n), C.byref(g), C.byref(m), C.byref(c)))
+        return n.value, g.value, m.value, c.value
+
+    def denoise_filter(self):
+        """rank 0 of a sharded frame, after the inputs have been summed over the ranks: temporal + a-trous + composite"""
+        _check(A.lib().lpt_renderer_denoise_filter(self._h))
+
     def frame_state(self):
         fc, seed = C.c_uint32(), C.c_uint32()
         _check(A.lib().lpt_renderer_get_frame_state(self._h, C.byref(fc), C.byref(seed)))

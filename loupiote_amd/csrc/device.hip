@@ -95,6 +95,8 @@ struct lpt_renderer {
     uint32_t *den_hist[2]{};
     float2 *den_motion = nullptr;
     float4 *den_temp = nullptr;
+    float4 *den_noisy = nullptr;  // per-pixel sample radiance of the current frame (filter input; exchanged when sharded)
+    bool den_inputs_ready = false;
     int den_cur = 1;              // current_frame_back starts true (asvgf.rs:233); start() flips it
     CamBasis prev_cam{};          // prev_model_to_screen (renderer.rs:201,319,542-546), identity at start
     // per-stage timing: a ring of event sets (one per raytrace() call) harvested lazily, so
@@ -414,7 +416,9 @@ static void free_denoiser(lpt_renderer *r) {
     }
     if (r->den_motion) hipFree(r->den_motion);
     if (r->den_temp) hipFree(r->den_temp);
-    r->den_motion = nullptr; r->den_temp = nullptr;
+    if (r->den_noisy) hipFree(r->den_noisy);
+    r->den_motion = nullptr; r->den_temp = nullptr; r->den_noisy = nullptr;
+    r->den_inputs_ready = false;
     r->den_cur = 1;
 }
 
@@ -434,6 +438,8 @@ static int ensure_denoiser(lpt_renderer *r) {
     }
     HIP_TRY(hipMalloc(&r->den_motion, sizeof(float2) * n));
     HIP_TRY(hipMalloc(&r->den_temp, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->den_noisy, sizeof(float4) * n));
+    HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * n, s));
     HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * n, s));
     return LPT_OK;
 }
@@ -699,6 +705,33 @@ static inline void stage_end(lpt_renderer *r) {
 
 int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) { return lpt_renderer_raytrace_n(r, view, 1u); }
 
+}  // extern "C"
+
+// asvgf.render (renderer.rs:513-518, asvgf.rs:250-291) / asvgf.temporal_pass (:519-522) over the whole frame, from the
+// per-pixel inputs (noisy radiance, G-buffer, motion) of the current frame
+static void launch_filter(lpt_renderer *r, hipStream_t s) {
+    if (r->mode != LPT_BLIT_DENOISED && r->mode != LPT_BLIT_TEMPORAL) return;  // debug views read the inputs directly (:539)
+    const int cur = r->den_cur, prv = 1 - r->den_cur;
+    const uint32_t npx = r->w * r->h;
+    const uint32_t px_blocks = div_up(npx, kBlock);
+    const uint32_t stream_blocks = std::min<uint32_t>(px_blocks, (uint32_t)r->dev->compute_units * 8u);
+    hipLaunchKernelGGL(k_temporal, dim3(stream_blocks), dim3(kBlock), 0, s, (int)r->w, (int)r->h, r->den_noisy, r->den_gbuf[cur], r->den_gbuf[prv], r->den_motion,
+                       r->den_rad[prv], r->den_mom[prv], r->den_hist[prv], r->den_rad[cur], r->den_mom[cur], r->den_hist[cur]);
+    const float4 *result = r->den_rad[cur];
+    if (r->mode == LPT_BLIT_DENOISED) {
+        hipMemcpyAsync(r->den_temp, r->den_rad[cur], sizeof(float4) * npx, hipMemcpyDeviceToDevice, s);  // copy_texture_to_texture
+        // even number of a-trous calls: main <-> radiance_temp, result ends in radiance_temp (asvgf.rs:286-287)
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 1);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 2);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 4);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 8);
+        result = r->den_temp;
+    }
+    hipLaunchKernelGGL(k_composite, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], result, r->accum, npx);
+}
+
+extern "C" {
+
 int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_samples) {
     if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
     if (n_samples == 0u || n_samples > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace_n: n must be in [1,64]");
@@ -745,10 +778,16 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     const bool denoise = r->mode != LPT_BLIT_PATHTRACE;
     GBufArgs gb{};
     if (denoise) {
-        if (r->world != 1u) return fail(LPT_ERR_INVALID_ARG, "the denoising BlitModes need the whole frame on one GPU (world_size 1)");
         int st = ensure_denoiser(r);
         if (st != LPT_OK) return st;
         r->den_cur = 1 - r->den_cur;         // asvgf.start() (renderer.rs:467)
+        if (r->world != 1u) {
+            // sharded frame: this rank fills only its tiles; the rest must read as zero for the exchange
+            const size_t npx = (size_t)r->w * r->h;
+            HIP_TRY(hipMemsetAsync(r->den_gbuf[r->den_cur], 0, sizeof(uint4) * npx, s));
+            HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * npx, s));
+            HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * npx, s));
+        }
         gb.gbuf = r->den_gbuf[r->den_cur];
         gb.motion = r->den_motion;
         gb.cur.origin = p.origin; gb.cur.right = p.right; gb.cur.up = p.up; gb.cur.fwd = p.fwd; gb.cur.ax = p.ax; gb.cur.ay = p.ay;
@@ -821,25 +860,13 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
             stage_begin(r, ST_ACCUM);
             hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->accum);
             stage_end(r);
-        } else if (r->mode == LPT_BLIT_DENOISED || r->mode == LPT_BLIT_TEMPORAL) {
-            // asvgf.render (:513-518, asvgf.rs:250-291) / asvgf.temporal_pass (:519-522)
+        } else {
+            // per-pixel filter inputs; on a sharded frame (world > 1) the caller now exchanges noisy / gbuffer / motion
+            // (lpt_renderer_denoiser_inputs) and rank 0 calls lpt_renderer_denoise_filter
             stage_begin(r, ST_ASVGF);
-            const int cur = r->den_cur, prv = 1 - r->den_cur;
-            const uint32_t npx = r->w * r->h;
-            const uint32_t px_blocks = div_up(npx, kBlock);
-            hipLaunchKernelGGL(k_temporal, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->den_gbuf[cur], r->den_gbuf[prv], r->den_motion,
-                               r->den_rad[prv], r->den_mom[prv], r->den_hist[prv], r->den_rad[cur], r->den_mom[cur], r->den_hist[cur]);
-            const float4 *result = r->den_rad[cur];
-            if (r->mode == LPT_BLIT_DENOISED) {
-                HIP_TRY(hipMemcpyAsync(r->den_temp, r->den_rad[cur], sizeof(float4) * npx, hipMemcpyDeviceToDevice, s));  // copy_texture_to_texture
-                // even number of a-trous calls: main <-> radiance_temp, result ends in radiance_temp (asvgf.rs:286-287)
-                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 1);
-                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 2);
-                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 4);
-                hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 8);
-                result = r->den_temp;
-            }
-            hipLaunchKernelGGL(k_composite, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], result, r->accum, npx);
+            hipLaunchKernelGGL(k_den_scatter, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->den_noisy);
+            r->den_inputs_ready = true;
+            if (r->world == 1u) launch_filter(r, s);
             stage_end(r);
         }  // GBuffer / MotionVector: the primary pass has written the debug targets; nothing else runs (:539)
         hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, s, r->ctr, r->totals, nb);
@@ -927,6 +954,31 @@ int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion
     if (motion) HIP_TRY(hipMemcpy(motion, r->den_motion, sizeof(float2) * n, hipMemcpyDeviceToHost));
     if (radiance) HIP_TRY(hipMemcpy(radiance, r->den_rad[c], sizeof(float4) * n, hipMemcpyDeviceToHost));
     if (history) HIP_TRY(hipMemcpy(history, r->den_hist[c], sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return LPT_OK;
+}
+
+// Sharded frames (set_shard, world > 1) in a denoising BlitMode: raytrace() leaves this rank's part of the filter inputs —
+// noisy radiance (float4), G-buffer (uint4), motion (float2), zero outside its tiles — in full-frame buffers.  The host
+// sums them over the ranks (one reduce each; the tiles are disjoint, so the sum is a gather) into rank 0's buffers and
+// calls lpt_renderer_denoise_filter there, which runs the temporal / a-trous / composite passes over the whole frame.
+int lpt_renderer_denoiser_inputs(lpt_renderer *r, void **noisy, void **gbuffer, void **motion, size_t *n_pixels) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoiser_inputs: null");
+    if (!r->den_temp) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoiser_inputs: no denoising frame has been traced");
+    if (noisy) *noisy = r->den_noisy;
+    if (gbuffer) *gbuffer = r->den_gbuf[r->den_cur];
+    if (motion) *motion = r->den_motion;
+    if (n_pixels) *n_pixels = (size_t)r->w * r->h;
+    return LPT_OK;
+}
+
+int lpt_renderer_denoise_filter(lpt_renderer *r) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoise_filter: null");
+    if (!r->den_temp || !r->den_inputs_ready) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoise_filter: no denoising frame has been traced");
+    if (r->world == 1u) return LPT_OK;  // raytrace() has already filtered the frame
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    launch_filter(r, r->stream);
+    HIP_TRY(hipGetLastError());
+    r->den_inputs_ready = false;
     return LPT_OK;
 }
 

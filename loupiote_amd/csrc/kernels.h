@@ -912,18 +912,26 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
 
 // ------------------------------------------------------------------ denoiser passes (SPEC §15.2-15.4)
 // TemporalAccumulationPass (asvgf.rs:245-247): nearest reprojection + consistency test, moments, history
-__global__ __launch_bounds__(kBlock) void k_temporal(FrameParams p, const float4 *Lsum, const uint4 *g_cur, const uint4 *g_prev, const float2 *motion,
-                                                     const float4 *rad_prev, const float2 *mom_prev, const uint32_t *hist_prev,
-                                                     float4 *rad_cur, float2 *mom_cur, uint32_t *hist_cur) {
+// the frame's noisy radiance, per PIXEL (the path state is per slot of this rank's tiles): what the filter passes read,
+// and — with gbuffer and motion — what the ranks of a sharded frame exchange before rank 0 filters
+__global__ __launch_bounds__(kBlock) void k_den_scatter(FrameParams p, const float4 *Lsum, float4 *noisy) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    const int W = (int)p.width, H = (int)p.height;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
         uint32_t x, y;
         if (!slot_to_pixel(p, slot, x, y)) continue;
-        const size_t i = (size_t)y * W + x;
+        noisy[(size_t)y * p.width + x] = Lsum[slot];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_temporal(int W, int H, const float4 *noisy, const uint4 *g_cur, const uint4 *g_prev, const float2 *motion,
+                                                     const float4 *rad_prev, const float2 *mom_prev, const uint32_t *hist_prev,
+                                                     float4 *rad_cur, float2 *mom_cur, uint32_t *hist_cur) {
+    const uint32_t stride = gridDim.x * blockDim.x, npx = (uint32_t)(W * H);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
+        const uint32_t y = i / (uint32_t)W, x = i - y * (uint32_t)W;
         const uint4 g = g_cur[i];
         const f3 a = demod_albedo(g.w);
-        const float4 L = Lsum[slot];
+        const float4 L = noisy[i];
         const f3 il = mk3(L.x / a.x, L.y / a.y, L.z / a.z);
         const float lm = lum(il);
         const float2 mo = motion[i];

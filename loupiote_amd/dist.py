@@ -77,3 +77,36 @@ class OwnedTileGather:
                 if r != self.rank:
                     flat.index_copy_(0, self.all[r], self.recv[r][: self.counts[r]])
         return buf
+
+
+class DevView:
+    """a device pointer as a torch-importable buffer (__cuda_array_interface__): plumbing for the exchanges"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def exchange_denoiser_inputs(renderer, device, dst=0, stream=None):
+    """Sharded frame in a denoising BlitMode: sum every rank's filter inputs (noisy radiance, G-buffer, motion —
+    zero outside the rank's tiles, so the sum is a gather) onto `dst`, then run the filter passes there.
+    One RCCL reduce per buffer (float32 / int32 / float32), issued on `stream` (the renderer's) when given."""
+    import torch
+    import torch.distributed as dist
+    noisy, gbuf, motion, n = renderer.denoiser_inputs()
+    bufs = [torch.as_tensor(DevView(noisy, 4 * n, "<f4"), device=device), torch.as_tensor(DevView(gbuf, 4 * n, "<i4"), device=device),
+            torch.as_tensor(DevView(motion, 2 * n, "<f4"), device=device)]
+    ctx = torch.cuda.stream(stream) if stream is not None else _null()
+    with ctx:
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for b in bufs:
+                dist.reduce(b, dst=dst, op=dist.ReduceOp.SUM)
+    if not dist.is_initialized() or dist.get_rank() == dst:
+        renderer.denoise_filter()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; the loader keeps whichever copy is loaded first for the whole
+# process.  Tests that hand device pointers to torch (exchange plumbing) need torch's copy to be that one — the
+# order bench.py has anyway — so torch is imported before libloupiote_hip.so.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the pure C-ABI tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import loupiote_amd as lp
-from loupiote_amd import testing as T
+from loupiote_amd import dist as D, testing as T
 
 pytestmark = pytest.mark.gpu
 
@@ -85,8 +85,61 @@ def test_denoiser_reduces_noise_and_debug_views(device, cornell_glb):
     r.set_blit_mode(lp.BlitMode.MotionVector)
     r.raytrace(view)
     assert r.blit()[..., :2].max() == 0                          # static camera
-    with pytest.raises(lp.Error):                                # denoising needs the whole frame on one GPU
-        r.set_shard(0, 2)
-        r.set_resources(device, sg, pr)
-        r.raytrace(view)
     r.close(); pr.close(); sg.close()
+
+
+def test_sharded_denoising_equals_single_gpu(device, cornell_glb):
+    """Multi-GPU denoising (config 5): two tile shards (emulated on this GPU by two renderers) trace their tiles,
+    their filter inputs are summed (what `dist.exchange_denoiser_inputs` does with RCCL reduces) into rank 0's
+    buffers, rank 0 filters the whole frame — bit-identical to the single-GPU denoiser, frame after frame, with a
+    moving camera so that reprojection crosses tile borders."""
+    import torch
+    from loupiote_amd.dist import DevView
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    W, H = 160, 96
+
+    def make(rank, world):
+        r = lp.Renderer(device, (W, H))
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (W, H))
+        r.set_max_bounces(3)
+        r.set_vfov(T.VFOV)
+        if world > 1:
+            r.set_shard(rank, world)
+            r.set_resources(device, sg, pr)
+        r.set_blit_mode(lp.BlitMode.DenoisedPathrace)
+        return r
+
+    single, a, b = make(0, 1), make(0, 2), make(1, 2)
+    dev = torch.device("cuda", 0)
+
+    def views(r):
+        noisy, gbuf, motion, n = r.denoiser_inputs()
+        return [torch.as_tensor(DevView(noisy, 4 * n, "<f4"), device=dev), torch.as_tensor(DevView(gbuf, 4 * n, "<i4"), device=dev),
+                torch.as_tensor(DevView(motion, 2 * n, "<f4"), device=dev)]
+
+    for f in range(4):
+        eye = (0.15 * f, 0.6 + 0.05 * f, 13.5 - 0.2 * f)
+        view = T.look(eye, T.CORNELL_DIR)
+        for r in (single, a, b):
+            r.raytrace(view)
+            r.synchronize()
+        va, vb = views(a), views(b)
+        own = torch.from_numpy(D.owned_mask(W, H, 0, 2)).to(dev)
+        assert bool((va[0].view(H, W, 4)[~own] == 0).all()) and bool((vb[0].view(H, W, 4)[own] == 0).all())
+        for x, y in zip(va, vb):
+            x += y                                    # the reduce (sum over ranks) onto rank 0
+        torch.cuda.synchronize()
+        a.denoise_filter()
+        assert a.read_radiance().tobytes() == single.read_radiance().tobytes(), "frame %d" % f
+        ga, ma, ra, ha = a.read_denoiser()
+        gs, ms, rs, hs = single.read_denoiser()
+        assert ga.tobytes() == gs.tobytes() and ma.tobytes() == ms.tobytes() and ra.tobytes() == rs.tobytes() and ha.tobytes() == hs.tobytes()
+    assert ha.max() == 4
+    for r in (single, a, b):
+        r.close()
+    pr.close(); sg.close()
