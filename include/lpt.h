@@ -232,6 +232,12 @@ int lpt_load_gltf_path(lpt_scene *scene, const char *path);
  * (crates/standalone/src/app.rs:172-187): writes RGBA8 rows (e.g. from lpt_renderer_read_pixels) as a PNG. */
 int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32_t height, size_t row_bytes);
 
+/* replaces: the `image::codecs::hdr::HdrDecoder` step of ApplicationContext::load_env
+ * (crates/standalone/src/app.rs:138-155): Radiance RGBE (.hdr) bytes -> the 4-byte RGBE pixels ProbeGPU::new takes,
+ * rows top to bottom.  Call with rgbe8 == NULL to get the size, then with a buffer of width*height*4 bytes.
+ * LPT_ERR_FILE_NOT_FOUND when the data is not a decodable "-Y H +X W" 32-bit_rle_rgbe image. */
+int lpt_decode_hdr(const uint8_t *data, size_t size, uint8_t *rgbe8, size_t capacity, uint32_t *width, uint32_t *height);
+
 /* ---- SceneGPU / ProbeGPU --------------------------------------------------
  * replaces: SceneGPU::new_from_scene(&Scene,&Device,&Queue)
  * (crates/lib/src/scene.rs:151-188).  Bakes every instance into world space,

@@ -426,6 +426,22 @@ class loaders:
         _check(A.lib().lpt_load_gltf_path(scene._h, str(path).encode()))
 
 
+def load_env(data):
+    """the decoding half of ApplicationContext::load_env (crates/standalone/src/app.rs:138-155): Radiance .hdr bytes ->
+    (h, w, 4) uint8 RGBE pixels, ready for `ProbeGPU(device, pixels, w, h)`"""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(A.lib().lpt_decode_hdr(A.ptr(buf), buf.size, None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    _check(A.lib().lpt_decode_hdr(A.ptr(buf), buf.size, A.ptr(out), out.size, C.byref(w), C.byref(h)))
+    return out
+
+
+def load_env_path(path):
+    with open(path, "rb") as f:
+        return load_env(f.read())
+
+
 def save_screenshot(renderer, path):
     """ApplicationContext::save_screenshot (crates/standalone/src/app.rs:172-187): read_pixels -> PNG file"""
     px = renderer.read_pixels()

@@ -78,4 +78,7 @@ bool decode_png(const uint8_t *data, size_t size, Image &out);
 // jpeg.cpp
 bool decode_jpeg(const uint8_t *data, size_t size, Image &out);
 
+// hdr.cpp
+bool decode_hdr(const uint8_t *data, size_t size, uint32_t &width, uint32_t &height, std::vector<uint8_t> &rgbe);
+
 }  // namespace lpt

@@ -389,3 +389,53 @@ def bake(scene):
     if not verts:
         return np.zeros(0, VERTEX_DT), np.zeros(0, np.uint32)
     return np.concatenate(verts), np.concatenate(mats)
+
+
+def decode_hdr(data):
+    """Radiance RGBE (.hdr) -> (h, w, 4) uint8 RGBE pixels, the bytes `image::codecs::hdr::HdrDecoder::read_image_native`
+    hands to ProbeGPU::new (reference crates/standalone/src/app.rs:138-155).  Plain restatement of the format:
+    text header up to an empty line, "-Y H +X W", then per scanline either the new RLE (2 2 hi lo, four channel planes
+    of runs / literals), or flat pixels with old-style (1,1,1,n) repeat markers."""
+    data = bytes(data)
+    pos = data.index(b"\n") + 1
+    if not data.startswith(b"#?"):
+        raise ValueError("not a Radiance file")
+    while True:
+        end = data.index(b"\n", pos)
+        line = data[pos:end].rstrip(b"\r")
+        pos = end + 1
+        if not line:
+            break
+        if line.startswith(b"FORMAT=") and line != b"FORMAT=32-bit_rle_rgbe":
+            raise ValueError("unsupported FORMAT")
+    end = data.index(b"\n", pos)
+    parts = data[pos:end].split()
+    pos = end + 1
+    if len(parts) != 4 or parts[0] != b"-Y" or parts[2] != b"+X":
+        raise ValueError("unsupported orientation")
+    H, W = int(parts[1]), int(parts[3])
+    out = np.zeros((H, W, 4), np.uint8)
+    for y in range(H):
+        if 8 <= W < 32768 and data[pos] == 2 and data[pos + 1] == 2 and (data[pos + 2] << 8 | data[pos + 3]) == W:
+            pos += 4
+            for ch in range(4):
+                x = 0
+                while x < W:
+                    c = data[pos]; pos += 1
+                    if c > 128:
+                        c -= 128
+                        out[y, x:x + c, ch] = data[pos]; pos += 1
+                    else:
+                        out[y, x:x + c, ch] = np.frombuffer(data, np.uint8, c, pos); pos += c
+                    x += c
+        else:
+            x, shift = 0, 0
+            while x < W:
+                p = data[pos:pos + 4]; pos += 4
+                if p[0] == 1 and p[1] == 1 and p[2] == 1:
+                    n = p[3] << shift
+                    out[y, x:x + n] = out[y, x - 1]
+                    x += n; shift += 8
+                else:
+                    out[y, x] = np.frombuffer(p, np.uint8); x += 1; shift = 0
+    return out

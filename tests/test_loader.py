@@ -246,3 +246,56 @@ def test_jpeg_grey_and_unsupported_modes():
         with pytest.raises(lp.Error) as e:
             lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[broken], textures=[0]), lp.Scene())
         assert e.value.kind == "FileNotFound"
+
+
+def _hdr_bytes(px, rle=True, header=b"#?RADIANCE\nSOFTWARE=test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n"):
+    """write (h, w, 4) RGBE pixels as a Radiance file: new-style RLE scanlines (runs where a value repeats) or flat"""
+    h, w, _ = px.shape
+    out = bytearray(header + b"-Y %d +X %d\n" % (h, w))
+    for y in range(h):
+        if rle and 8 <= w < 32768:
+            out += bytes([2, 2, w >> 8, w & 255])
+            for ch in range(4):
+                row = px[y, :, ch]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        out += bytes([128 + run, int(row[x])]); x += run
+                    else:
+                        lit = 1
+                        while x + lit < w and lit < 128 and not (x + lit + 2 < w and row[x + lit] == row[x + lit + 1] == row[x + lit + 2]):
+                            lit += 1
+                        out += bytes([lit]) + row[x:x + lit].tobytes(); x += lit
+        else:
+            out += px[y].tobytes()
+    return bytes(out)
+
+
+def test_hdr_decoder_matches_oracle_and_source():
+    """load_env (app.rs:138-155): Radiance .hdr -> RGBE8 pixels; product == numpy restatement == what was encoded"""
+    rng = np.random.default_rng(11)
+    for (h, w) in [(5, 7), (16, 64), (9, 300)]:
+        px = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        px[:, w // 3: w // 3 + min(w // 2, 150)] = px[:, w // 3: w // 3 + 1]      # long runs
+        px[h // 2] = 128                                                      # a constant scanline
+        for rle in (True, False):
+            raw = _hdr_bytes(px, rle)
+            got = lp.load_env(raw)
+            assert got.tobytes() == px.tobytes() and G.decode_hdr(raw).tobytes() == px.tobytes()
+    # old-style runs inside flat scanlines: pixel, then (1,1,1,n) repeats it n times
+    px = np.zeros((2, 10, 4), np.uint8)
+    px[0, :] = (10, 20, 30, 129); px[1, :4] = (1, 2, 3, 128); px[1, 4:] = (9, 8, 7, 130)
+    raw = b"#?RGBE\n\n-Y 2 +X 10\n" + bytes([10, 20, 30, 129, 1, 1, 1, 9]) + bytes([1, 2, 3, 128, 1, 1, 1, 3, 9, 8, 7, 130, 1, 1, 1, 5])
+    assert lp.load_env(raw).tobytes() == px.tobytes() and G.decode_hdr(raw).tobytes() == px.tobytes()
+    # the synthetic sky probe survives a file round trip and uploads as a probe
+    from loupiote_amd import scenes
+    sky = scenes.sky_probe(64, 32)
+    assert lp.load_env(_hdr_bytes(sky)).tobytes() == sky.tobytes()
+    for bad in (b"", b"#?RADIANCE\n\n-Y 2 +X 2\n\x00", b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 1 +X 1\n\x00\x00\x00\x00",
+                b"#?RADIANCE\n\n+Y 1 +X 1\n\x00\x00\x00\x00", b"P6\n1 1\n255\n\x00\x00\x00", _hdr_bytes(sky)[:-9]):
+        with pytest.raises(lp.Error) as e:
+            lp.load_env(bad)
+        assert e.value.kind == "FileNotFound"
