@@ -69,6 +69,13 @@ class Scene {  // scene.rs:30-54
 namespace loaders {  // loaders/gltf.rs:46-161
 inline void load_gltf(const uint8_t *data, size_t size, Scene &scene) { check(lpt_load_gltf(scene.handle(), data, size)); }
 inline void load_gltf_path(const std::string &path, Scene &scene) { check(lpt_load_gltf_path(scene.handle(), path.c_str())); }
+/// the decoding half of ApplicationContext::load_env (app.rs:138-155): Radiance .hdr bytes -> RGBE8 pixels for ProbeGPU
+inline std::vector<uint8_t> load_env(const uint8_t *data, size_t size, uint32_t &width, uint32_t &height) {
+    check(lpt_decode_hdr(data, size, nullptr, 0, &width, &height));
+    std::vector<uint8_t> px((size_t)width * height * 4);
+    check(lpt_decode_hdr(data, size, px.data(), px.size(), &width, &height));
+    return px;
+}
 }  // namespace loaders
 
 class SceneGPU {  // scene.rs:56-64,151-188
