@@ -270,7 +270,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, view, os.cpu_count() or 1)
         elif world > 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -279,6 +280,16 @@ def main():
     probe.close()
     sg.close()
     dev.close()
+    if out is not None:
+        # RCCL writes its version banner to stdout through C stdio: push that out first so that the JSON line is the
+        # last thing on rank 0's stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
