@@ -96,7 +96,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dev = lp.Device(local_rank)
-    desc = scenes.synthetic_atrium()
+    desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"))
     scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, dev)
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
