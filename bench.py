@@ -47,7 +47,8 @@ def cpu_baseline(desc, view, threads):
     whole 1920x1080 frames of 1 spp each (the same seeds the GPU step uses for its 1st, 2nd ... sample),
     as many of the 4 as fit in ~15 s of wall time."""
     from oracle import orc  # checker only: the baseline leg, never the product path
-    s = scenes.to_oracle(desc)
+    from oracle import harness
+    s = harness.to_oracle(desc)
     sc = orc.OracleScene.from_scene(s, probe=desc["probe"])
     rays, secs, frames = 0, 0.0, 0
     while frames < SPP and secs < 15.0:

@@ -11,8 +11,8 @@ with the reference or exist on this machine, so BASELINE configs 3-5 run on the 
   synthetic_helmet(seed=1) — DamagedHelmet stand-in: a displaced icosphere (~70k tris), textured.
 
 A scene description is a plain dict of numpy arrays; `to_product` feeds it through the C ABI
-(`Scene.add_mesh / add_instance / ...`) and `to_oracle` feeds the same arrays to the oracle's
-numpy Scene, so both sides start from identical bytes.
+(`Scene.add_mesh / add_instance / ...`); the tests feed the same arrays to the oracle's numpy Scene
+(`oracle/harness.py: to_oracle`), so both sides start from identical bytes.
 """
 import numpy as np
 
@@ -322,24 +322,4 @@ def to_product(desc):
             s.set_light(0, l)
         else:
             s.add_light(l)
-    return s
-
-
-def to_oracle(desc):
-    """same arrays into the oracle's numpy Scene (tests / cpu_baseline only)"""
-    from oracle import gltf_oracle as G
-    s = G.Scene()
-    for m in desc["meshes"]:
-        s.add_mesh(m["positions"], m["normals"], m["uvs"], m["indices"])
-    for color, rough, metal, at, mt in desc["materials"]:
-        s.add_material(color, rough, metal, at, mt)
-    for img in desc["images"]:
-        s.images.append(img)
-    for blas, mat16, material in desc["instances"]:
-        s.add_instance(blas, mat16, material)
-    for i, l in enumerate(desc["lights"]):
-        if i == 0:
-            s.lights[0] = np.asarray(l, G.LIGHT_DT)[0]
-        else:
-            s.lights = np.concatenate([s.lights, np.asarray(l, G.LIGHT_DT)])
     return s

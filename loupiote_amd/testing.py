@@ -1,7 +1,5 @@
-"""Shared scene/camera setup for tests, smoke() and bench.py (host-side plumbing only).
-
-`render_oracle` is the only function here that touches oracle/, and it imports it lazily:
-it is called from tests/, smoke() and bench.py's cpu_baseline leg, never by the product path."""
+"""Shared scene/camera setup for tests, smoke() and bench.py (host-side plumbing only; the oracle-side
+counterpart lives in oracle/harness.py — nothing in this package imports oracle/)."""
 import numpy as np
 
 from . import api
@@ -58,15 +56,3 @@ def render_hip(dev, glb, width, height, bounces, frames, seed=0, rank=0, world=1
         pr.close()
     sg.close()
     return img, counts
-
-
-def render_oracle(glb, width, height, bounces, frames, seed=0, rank=0, world=1, light=None, probe=CORNELL_PROBE,
-                  eye=CORNELL_EYE, direction=CORNELL_DIR, brute_force=False, threads=None):
-    from oracle import gltf_oracle as G, orc  # test infrastructure: lazy on purpose
-    s = G.Scene()
-    G.load_gltf(glb, s)
-    s.lights[0] = (cornell_light() if light is None else light)[0]
-    sc = orc.OracleScene.from_scene(s, probe=probe)
-    acc, cnt = sc.render(width, height, look(eye, direction), VFOV, bounces, frames=frames, user_seed=seed,
-                         rank=rank, world_size=world, brute_force=brute_force, threads=threads, want_counters=True)
-    return orc.resolve(acc), cnt

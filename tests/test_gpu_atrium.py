@@ -5,6 +5,7 @@ import pytest
 
 import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
+from oracle import harness
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -14,7 +15,7 @@ TOL = 1e-5
 def atrium():
     from oracle import orc
     desc = scenes.synthetic_atrium()
-    osc = orc.OracleScene.from_scene(scenes.to_oracle(desc), probe=desc["probe"])
+    osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
     return desc, osc
 
 
@@ -113,7 +114,7 @@ def test_blue_noise_mode_matches_oracle(device, atrium):
     from oracle import orc
     desc, _ = atrium
     noise = np.random.default_rng(5).integers(0, 256, (64, 64, 4), dtype=np.uint8)
-    osc = orc.OracleScene.from_scene(scenes.to_oracle(desc), probe=desc["probe"], noise=noise)
+    osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"], noise=noise)
     w, h, bounces, frames = 160, 96, 4, 2
     img, counts, _ = render_desc(device, desc, w, h, bounces, frames, noise=noise)
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])

@@ -11,6 +11,7 @@ import pytest
 
 import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
+from oracle import harness
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +29,7 @@ def _renderer(device, desc, w, h, bounces):
 
 def test_config2_cornell_1024_4spp_depth8(device, cornell_glb):
     img, counts = T.render_hip(device, cornell_glb, 1024, 1024, 8, 4)
-    ref, oc = T.render_oracle(cornell_glb, 1024, 1024, 8, 4)
+    ref, oc = harness.render_oracle(cornell_glb, 1024, 1024, 8, 4)
     assert (counts.closest, counts.shadow, counts.shaded) == (oc.closest, oc.shadow, oc.shaded)
     assert img.tobytes() == ref.tobytes()
 
@@ -37,7 +38,7 @@ def test_config3_helmet_standin(device):
     from oracle import orc
     desc = scenes.synthetic_helmet()
     assert desc["triangles"] > 69000 and len(desc["images"]) == 2
-    osc = orc.OracleScene.from_scene(scenes.to_oracle(desc), probe=desc["probe"])
+    osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
     sg, pr, r, view = _renderer(device, desc, 480, 270, 8)
     r.reset_accumulation()
     r.accumulate = True

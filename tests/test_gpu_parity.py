@@ -8,6 +8,7 @@ import pytest
 
 import loupiote_amd as lp
 from loupiote_amd import testing as T
+from oracle import harness
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +53,7 @@ def test_closest_hit_matches_oracle_cornell(device, cornell_glb):
 @pytest.mark.parametrize("size,bounces,frames", [(256, 4, 1), (128, 8, 3)])
 def test_cornell_radiance_matches_oracle(device, cornell_glb, size, bounces, frames):
     img, counts = T.render_hip(device, cornell_glb, size, size, bounces, frames)
-    ref, oc = T.render_oracle(cornell_glb, size, size, bounces, frames)
+    ref, oc = harness.render_oracle(cornell_glb, size, size, bounces, frames)
     assert (counts.closest, counts.shadow, counts.shaded) == (oc.closest, oc.shadow, oc.shaded)
     mism = np.mean(np.any(img != ref, axis=2))
     print("bit-mismatching pixels: %.4f%%  max|err| = %g" % (100 * mism, np.max(np.abs(img - ref))))

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from loupiote_amd import dist, scenes, testing as T
-from oracle import gltf_oracle as G, orc
+from oracle import gltf_oracle as G, harness, orc
 
 L = orc.lib()
 
@@ -338,22 +338,22 @@ def test_environment_only_energy_bound_and_miss():
 
 
 def test_determinism_threads_and_bvh_invariance(cornell_glb):
-    a, ca = T.render_oracle(cornell_glb, 96, 64, 5, 2, threads=1)
-    b, cb = T.render_oracle(cornell_glb, 96, 64, 5, 2, threads=7)
-    c, cc = T.render_oracle(cornell_glb, 96, 64, 5, 2, brute_force=True)
+    a, ca = harness.render_oracle(cornell_glb, 96, 64, 5, 2, threads=1)
+    b, cb = harness.render_oracle(cornell_glb, 96, 64, 5, 2, threads=7)
+    c, cc = harness.render_oracle(cornell_glb, 96, 64, 5, 2, brute_force=True)
     assert a.tobytes() == b.tobytes() == c.tobytes()
     assert (ca.closest, ca.shadow) == (cb.closest, cb.shadow) == (cc.closest, cc.shadow)
-    d, _ = T.render_oracle(cornell_glb, 96, 64, 5, 2, seed=1)
+    d, _ = harness.render_oracle(cornell_glb, 96, 64, 5, 2, seed=1)
     assert a.tobytes() != d.tobytes()
 
 
 def test_tile_shards_sum_to_full_frame(cornell_glb):
     W, H = 200, 72
-    full, fc = T.render_oracle(cornell_glb, W, H, 3, 2)
+    full, fc = harness.render_oracle(cornell_glb, W, H, 3, 2)
     acc = np.zeros_like(full)
     total = 0
     for rank in range(3):
-        part, c = T.render_oracle(cornell_glb, W, H, 3, 2, rank=rank, world=3)
+        part, c = harness.render_oracle(cornell_glb, W, H, 3, 2, rank=rank, world=3)
         mask = dist.owned_mask(W, H, rank, 3)
         assert np.array_equal(part[..., 3] > 0, mask)   # ownership rule == dist.owner_map
         acc += part
@@ -367,7 +367,7 @@ def test_cornell_config1_golden_fixture(cornell_glb):
     tests/golden/make_golden.py from this oracle; they pin it against silent drift (and against libm / compiler
     differences between the dev container and the GPU host)."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_256_d4_s1.npz"))
-    img, cnt = T.render_oracle(cornell_glb, 256, 256, 4, 1)
+    img, cnt = harness.render_oracle(cornell_glb, 256, 256, 4, 1)
     assert (cnt.closest, cnt.shadow, cnt.shaded) == tuple(int(x) for x in g["counts"])
     assert np.array_equal(img[96:160, 96:160], g["crop"])
     assert hashlib.sha256(img.tobytes()).hexdigest() == str(g["sha256"])
