@@ -99,7 +99,7 @@ def main():
     dev = lp.Device(local_rank)
     desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"))
     scene = scenes.to_product(desc)
-    sg = lp.SceneGPU.new_from_scene(scene, dev)
+    sg = lp.SceneGPU.new_from_scene(scene, dev, gpu_build=bool(os.environ.get("LPT_BENCH_GPU_BUILD")))
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
     P = max(1, args.pipeline)

@@ -80,9 +80,9 @@ inline std::vector<uint8_t> load_env(const uint8_t *data, size_t size, uint32_t 
 
 class SceneGPU {  // scene.rs:56-64,151-188
    public:
-    static SceneGPU new_from_scene(const Scene &scene, const Device &device) {
+    static SceneGPU new_from_scene(const Scene &scene, const Device &device, bool gpu_build = false) {
         SceneGPU s;
-        check(lpt_scene_upload(device.inner(), scene.handle(), &s.h_));
+        check(lpt_scene_upload_ex(device.inner(), scene.handle(), gpu_build ? LPT_ACCEL_BUILD_GPU_LBVH : LPT_ACCEL_BUILD_HOST_SAH, &s.h_));
         return s;
     }
     SceneGPU(SceneGPU &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }

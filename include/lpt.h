@@ -245,6 +245,13 @@ int lpt_decode_hdr(const uint8_t *data, size_t size, uint8_t *rgbe8, size_t capa
  * materials / lights / image atlas into HBM.  The CPU scene stays with the
  * caller.  LPT_ERR_ACCEL_BUILD when the build fails. */
 int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out);
+/* new (the reference builds its BVH on the CPU at load time, loaders/gltf.rs:97-105): the same upload with
+ * a choice of builder.  LPT_ACCEL_BUILD_HOST_SAH = binned-SAH + SAH-optimal 8-wide collapse on the host (what
+ * lpt_scene_upload does); LPT_ACCEL_BUILD_GPU_LBVH = Morton-code radix tree collapsed to 8-wide nodes on the GPU
+ * (a few milliseconds; lower tree quality) for scenes that are rebuilt every frame.  Rendered results are identical. */
+#define LPT_ACCEL_BUILD_HOST_SAH 0u
+#define LPT_ACCEL_BUILD_GPU_LBVH 1u
+int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags, lpt_scene_gpu **out);
 int lpt_scene_gpu_destroy(lpt_scene_gpu *sg);
 /* replaces: Instance::set_transform + a new SceneGPU (crates/standalone/src/lib.rs:118-121, scene.rs:151):
  * after lpt_scene_set_instance_transform on the CPU scene, re-bakes only the changed instances and refits the

@@ -195,9 +195,11 @@ class SceneGPU:
         self._dev = device
 
     @classmethod
-    def new_from_scene(cls, scene, device):
+    def new_from_scene(cls, scene, device, gpu_build=False):
+        """scene.rs:151 `SceneGPU::new_from_scene`; gpu_build=True builds the BVH on the GPU (Morton radix tree, a few
+        ms, lower quality) instead of the host SAH builder — for scenes that are rebuilt every frame"""
         h = C.c_void_p()
-        _check(A.lib().lpt_scene_upload(device.inner(), scene._h, C.byref(h)))
+        _check(A.lib().lpt_scene_upload_ex(device.inner(), scene._h, 1 if gpu_build else 0, C.byref(h)))
         return cls(h, device)
 
     def stats(self):

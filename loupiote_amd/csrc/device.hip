@@ -13,6 +13,8 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "build_kernels.h"
+#include <hipcub/hipcub.hpp>
 
 using namespace lpt;
 using namespace lptd;
@@ -122,6 +124,108 @@ static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
     return LPT_OK;
 }
 
+// ---------------------------------------------------------------------------- GPU builder (build_kernels.h)
+// Fills sg->nodes / woop / leaf_prim / tri_slot / node_lo / node_hi / level_start from the baked triangles that are
+// already on the device (sg->d.tri_verts).  `woop_prim` = the Woop maps in prim order (host, SPEC §6).
+static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
+    const uint32_t n = (uint32_t)acc.tri_material.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (const lpt_vertex &v : acc.tri_verts)
+        for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], v.position[a]); bhi[a] = std::max(bhi[a], v.position[a]); }
+    float binv[3];
+    for (int a = 0; a < 3; ++a) binv[a] = bhi[a] > blo[a] ? 1.0f / (bhi[a] - blo[a]) : 0.0f;
+
+    std::vector<void *> tmp;  // scratch, freed on every exit
+    auto scratch = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
+    auto done = [&](int st) { hipStreamSynchronize(s); for (void *p : tmp) hipFree(p); return st; };
+#define SCR(type, name, count) type *name = (type *)scratch(sizeof(type) * (size_t)(count)); if (!name) return done(fail(LPT_ERR_HIP, "GPU BVH build: out of device memory"));
+    SCR(uint32_t, keys, n) SCR(uint32_t, vals, n) SCR(uint32_t, keys_s, n) SCR(uint32_t, vals_s, n)
+    LbvhTree T{};
+    SCR(int, t_left, n) SCR(int, t_right, n) SCR(int, t_parent, n) SCR(int, t_leafp, n)
+    SCR(uint32_t, t_first, n) SCR(uint32_t, t_last, n) SCR(float4, t_lo, n) SCR(float4, t_hi, n) SCR(float4, t_tlo, n) SCR(float4, t_thi, n) SCR(uint32_t, t_flag, n)
+    T.left = t_left; T.right = t_right; T.parent = t_parent; T.leaf_parent = t_leafp; T.first = t_first; T.last = t_last;
+    T.lo = t_lo; T.hi = t_hi; T.tri_lo = t_tlo; T.tri_hi = t_thi; T.flag = t_flag; T.sorted_tri = vals_s; T.keys = keys_s; T.n = n;
+    const uint32_t b256 = div_up(n, 256u);
+    hipLaunchKernelGGL(k_lbvh_morton, dim3(b256), dim3(256), 0, s, sg->d, n, make_float3(blo[0], blo[1], blo[2]), make_float3(binv[0], binv[1], binv[2]), keys, vals);
+    size_t sort_bytes = 0;
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_s, vals, vals_s, (int)n, 0, 30, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: sort setup failed"));
+    size_t scan_bytes = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: scan setup failed"));
+    void *cub_tmp = scratch(std::max(sort_bytes, scan_bytes));
+    if (!cub_tmp) return done(fail(LPT_ERR_HIP, "GPU BVH build: out of device memory"));
+    size_t cub_bytes = std::max(sort_bytes, scan_bytes);
+    if (hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys, keys_s, vals, vals_s, (int)n, 0, 30, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: sort failed"));
+    hipLaunchKernelGGL(k_lbvh_leaf_boxes, dim3(b256), dim3(256), 0, s, sg->d, T);
+    HIP_TRY(hipMemsetAsync(t_flag, 0, sizeof(uint32_t) * n, s));
+    hipLaunchKernelGGL(k_lbvh_tree, dim3(b256), dim3(256), 0, s, T);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3(b256), dim3(256), 0, s, T);
+
+    // wide tree, level by level
+    SCR(uint4, nodes_big, 5u * (size_t)n)           // <= n-1 wide nodes
+    SCR(int, items_a, n) SCR(int, items_b, n) SCR(int, kid_ref, 8u * (size_t)n)
+    SCR(uint32_t, inner_count, n) SCR(uint32_t, tri_count, n) SCR(uint32_t, inner_off, n) SCR(uint32_t, tri_off, n)
+    void *leaf_prim = nullptr, *tri_slot = nullptr;
+    HIP_TRY(hipMalloc(&leaf_prim, sizeof(uint32_t) * n));
+    sg->leaf_prim = leaf_prim;
+    HIP_TRY(hipMalloc(&tri_slot, sizeof(uint32_t) * n));
+    sg->tri_slot = tri_slot;
+    HIP_TRY(hipMemsetAsync(items_a, 0, sizeof(int), s));  // level 0 = the binary root
+    int *items_cur = items_a, *items_next = items_b;
+    uint32_t n_items = 1, level_first = 0, tri_running = 0;
+    sg->level_start.clear();
+    while (n_items) {
+        if (sg->level_start.size() > 64) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: tree deeper than 64 levels"));
+        LbvhLevel L{items_cur, n_items, kid_ref, inner_count, tri_count};
+        hipLaunchKernelGGL(k_lbvh_collapse, dim3(div_up(n_items, 64u)), dim3(64), 0, s, T, L);
+        cub_bytes = std::max(sort_bytes, scan_bytes);
+        hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, inner_count, inner_off, (int)n_items, s);
+        cub_bytes = std::max(sort_bytes, scan_bytes);
+        hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, tri_count, tri_off, (int)n_items, s);
+        uint32_t tail[4];
+        HIP_TRY(hipMemcpyAsync(&tail[0], inner_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&tail[1], inner_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&tail[2], tri_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&tail[3], tri_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t inner_total = tail[0] + tail[1], tri_total = tail[2] + tail[3];
+        if ((size_t)level_first + n_items + inner_total > n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: node budget exceeded"));
+        hipLaunchKernelGGL(k_lbvh_emit, dim3(div_up(n_items, 64u)), dim3(64), 0, s, T, L, inner_off, tri_off, level_first, level_first + n_items, tri_running,
+                           nodes_big, (uint32_t *)leaf_prim, (uint32_t *)tri_slot, items_next);
+        sg->level_start.push_back(level_first);
+        level_first += n_items;
+        tri_running += tri_total;
+        n_items = inner_total;
+        std::swap(items_cur, items_next);
+    }
+    sg->level_start.push_back(level_first);
+    if (tri_running != n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: %u of %u triangles referenced", tri_running, n));
+    const uint32_t n_nodes = level_first;
+    HIP_TRY(hipMalloc(&sg->nodes, sizeof(Node8) * (size_t)n_nodes));
+    HIP_TRY(hipMemcpyAsync(sg->nodes, nodes_big, sizeof(Node8) * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMalloc(&sg->node_lo, sizeof(float4) * (size_t)n_nodes));
+    HIP_TRY(hipMalloc(&sg->node_hi, sizeof(float4) * (size_t)n_nodes));
+    // Woop maps: prim order (host, double precision) -> leaf order
+    HIP_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)n));
+    SCR(float4, woop_prim, 3u * (size_t)n)
+    HIP_TRY(hipMemcpyAsync(woop_prim, acc.woop.data(), sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(b256), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)tri_slot, n);
+    sg->d.nodes = (const DNode8 *)sg->nodes;
+    sg->d.leaf_prim = (const uint32_t *)sg->leaf_prim;
+    sg->d.woop = (const float4 *)sg->woop;
+    for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
+        const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
+        if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
+    }
+    HIP_TRY(hipGetLastError());
+    sg->stats.nodes = n_nodes;
+    sg->stats.max_depth = (uint32_t)sg->level_start.size() - 1u;
+    const int st = done(LPT_OK);
+    sg->stats.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+#undef SCR
+}
+
 extern "C" {
 
 // ============================================================================ Device
@@ -186,12 +290,21 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     return LPT_OK;
 }
 
-int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out) {
+int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **out) { return lpt_scene_upload_ex(dev, scene, LPT_ACCEL_BUILD_HOST_SAH, out); }
+
+int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags, lpt_scene_gpu **out) {
     if (!dev || !scene || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload: null");
+    if (flags > LPT_ACCEL_BUILD_GPU_LBVH) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload_ex: unknown flags %u", flags);
     HIP_TRY(hipSetDevice(dev->ordinal));
     Accel acc;
-    int st = bake_and_build(*scene, acc);
+    bool gpu_build = flags == LPT_ACCEL_BUILD_GPU_LBVH;
+    int st = gpu_build ? bake_only(*scene, acc) : bake_and_build(*scene, acc);
     if (st != LPT_OK) return st;
+    if (gpu_build && acc.tri_material.size() < 16) {  // tiny scenes: the host builder (a radix tree needs >= 2 leaves)
+        gpu_build = false;
+        st = bake_and_build(*scene, acc);
+        if (st != LPT_OK) return st;
+    }
     lpt_scene_gpu *sg = new lpt_scene_gpu();
     sg->dev = dev;
     hipStream_t s = dev->stream;
@@ -200,9 +313,11 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
         lpt_scene_gpu_destroy(sg);                                             \
         return st;                                                             \
     }
-    UP(nodes, acc.nodes)
-    UP(woop, acc.woop)
-    UP(leaf_prim, acc.leaf_prim)
+    if (!gpu_build) {
+        UP(nodes, acc.nodes)
+        UP(woop, acc.woop)
+        UP(leaf_prim, acc.leaf_prim)
+    }
     UP(tri_verts, acc.tri_verts)
     UP(tri_material, acc.tri_material)
     UP(materials, scene->materials)
@@ -224,13 +339,15 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
         lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
     }
     UP(srgb_lut, lut)
-    std::vector<uint32_t> tri_slot(acc.leaf_prim.size(), 0u);
-    if (!acc.tri_material.empty())
-        for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
-    UP(tri_slot, tri_slot)
-    std::vector<float4> boxes(acc.nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));  // filled by the first refit
-    UP(node_lo, boxes)
-    UP(node_hi, boxes)
+    if (!gpu_build) {
+        std::vector<uint32_t> tri_slot(acc.leaf_prim.size(), 0u);
+        if (!acc.tri_material.empty())
+            for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
+        UP(tri_slot, tri_slot)
+        std::vector<float4> boxes(acc.nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));  // filled by the first refit
+        UP(node_lo, boxes)
+        UP(node_hi, boxes)
+    }
 #undef UP
     sg->inst_first = acc.inst_first; sg->inst_count = acc.inst_count; sg->level_start = acc.level_start;
     sg->instances = scene->instances;
@@ -261,6 +378,11 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
     sg->stats.tri_bytes = (uint32_t)sizeof(WoopTri);
     sg->stats.max_depth = acc.max_depth;
     sg->stats.build_ms = acc.build_ms;
+    if (gpu_build) {
+        st = build_lbvh(sg, acc, s);
+        if (st != LPT_OK) { lpt_scene_gpu_destroy(sg); return st; }
+        d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
+    }
     *out = sg;
     return LPT_OK;
 }
