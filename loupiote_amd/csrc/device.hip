@@ -139,6 +139,7 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     std::vector<void *> tmp;  // scratch, freed on every exit
     auto scratch = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
     auto done = [&](int st) { hipStreamSynchronize(s); for (void *p : tmp) hipFree(p); return st; };
+#define LB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: %s", hipGetErrorString(e_))); } while (0)
 #define SCR(type, name, count) type *name = (type *)scratch(sizeof(type) * (size_t)(count)); if (!name) return done(fail(LPT_ERR_HIP, "GPU BVH build: out of device memory"));
     SCR(uint32_t, keys, n) SCR(uint32_t, vals, n) SCR(uint32_t, keys_s, n) SCR(uint32_t, vals_s, n)
     LbvhTree T{};
@@ -157,7 +158,7 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     size_t cub_bytes = std::max(sort_bytes, scan_bytes);
     if (hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys, keys_s, vals, vals_s, (int)n, 0, 30, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: sort failed"));
     hipLaunchKernelGGL(k_lbvh_leaf_boxes, dim3(b256), dim3(256), 0, s, sg->d, T);
-    HIP_TRY(hipMemsetAsync(t_flag, 0, sizeof(uint32_t) * n, s));
+    LB_TRY(hipMemsetAsync(t_flag, 0, sizeof(uint32_t) * n, s));
     hipLaunchKernelGGL(k_lbvh_tree, dim3(b256), dim3(256), 0, s, T);
     hipLaunchKernelGGL(k_lbvh_fit, dim3(b256), dim3(256), 0, s, T);
 
@@ -166,11 +167,11 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     SCR(int, items_a, n) SCR(int, items_b, n) SCR(int, kid_ref, 8u * (size_t)n)
     SCR(uint32_t, inner_count, n) SCR(uint32_t, tri_count, n) SCR(uint32_t, inner_off, n) SCR(uint32_t, tri_off, n)
     void *leaf_prim = nullptr, *tri_slot = nullptr;
-    HIP_TRY(hipMalloc(&leaf_prim, sizeof(uint32_t) * n));
+    LB_TRY(hipMalloc(&leaf_prim, sizeof(uint32_t) * n));
     sg->leaf_prim = leaf_prim;
-    HIP_TRY(hipMalloc(&tri_slot, sizeof(uint32_t) * n));
+    LB_TRY(hipMalloc(&tri_slot, sizeof(uint32_t) * n));
     sg->tri_slot = tri_slot;
-    HIP_TRY(hipMemsetAsync(items_a, 0, sizeof(int), s));  // level 0 = the binary root
+    LB_TRY(hipMemsetAsync(items_a, 0, sizeof(int), s));  // level 0 = the binary root
     int *items_cur = items_a, *items_next = items_b;
     uint32_t n_items = 1, level_first = 0, tri_running = 0;
     sg->level_start.clear();
@@ -183,11 +184,11 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
         cub_bytes = std::max(sort_bytes, scan_bytes);
         hipcub::DeviceScan::ExclusiveSum(cub_tmp, cub_bytes, tri_count, tri_off, (int)n_items, s);
         uint32_t tail[4];
-        HIP_TRY(hipMemcpyAsync(&tail[0], inner_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&tail[1], inner_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&tail[2], tri_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&tail[3], tri_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        LB_TRY(hipMemcpyAsync(&tail[0], inner_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        LB_TRY(hipMemcpyAsync(&tail[1], inner_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        LB_TRY(hipMemcpyAsync(&tail[2], tri_off + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        LB_TRY(hipMemcpyAsync(&tail[3], tri_count + (n_items - 1), 4, hipMemcpyDeviceToHost, s));
+        LB_TRY(hipStreamSynchronize(s));
         const uint32_t inner_total = tail[0] + tail[1], tri_total = tail[2] + tail[3];
         if ((size_t)level_first + n_items + inner_total > n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: node budget exceeded"));
         hipLaunchKernelGGL(k_lbvh_emit, dim3(div_up(n_items, 64u)), dim3(64), 0, s, T, L, inner_off, tri_off, level_first, level_first + n_items, tri_running,
@@ -201,14 +202,14 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     sg->level_start.push_back(level_first);
     if (tri_running != n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: %u of %u triangles referenced", tri_running, n));
     const uint32_t n_nodes = level_first;
-    HIP_TRY(hipMalloc(&sg->nodes, sizeof(Node8) * (size_t)n_nodes));
-    HIP_TRY(hipMemcpyAsync(sg->nodes, nodes_big, sizeof(Node8) * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMalloc(&sg->node_lo, sizeof(float4) * (size_t)n_nodes));
-    HIP_TRY(hipMalloc(&sg->node_hi, sizeof(float4) * (size_t)n_nodes));
+    LB_TRY(hipMalloc(&sg->nodes, sizeof(Node8) * (size_t)n_nodes));
+    LB_TRY(hipMemcpyAsync(sg->nodes, nodes_big, sizeof(Node8) * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
+    LB_TRY(hipMalloc(&sg->node_lo, sizeof(float4) * (size_t)n_nodes));
+    LB_TRY(hipMalloc(&sg->node_hi, sizeof(float4) * (size_t)n_nodes));
     // Woop maps: prim order (host, double precision) -> leaf order
-    HIP_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)n));
+    LB_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)n));
     SCR(float4, woop_prim, 3u * (size_t)n)
-    HIP_TRY(hipMemcpyAsync(woop_prim, acc.woop.data(), sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
+    LB_TRY(hipMemcpyAsync(woop_prim, acc.woop.data(), sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(b256), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)tri_slot, n);
     sg->d.nodes = (const DNode8 *)sg->nodes;
     sg->d.leaf_prim = (const uint32_t *)sg->leaf_prim;
@@ -217,12 +218,13 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
         const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
         if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
     }
-    HIP_TRY(hipGetLastError());
+    LB_TRY(hipGetLastError());
     sg->stats.nodes = n_nodes;
     sg->stats.max_depth = (uint32_t)sg->level_start.size() - 1u;
     const int st = done(LPT_OK);
     sg->stats.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
+#undef LB_TRY
 #undef SCR
 }
 
