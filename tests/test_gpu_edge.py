@@ -1,0 +1,118 @@
+"""-m gpu: edge cases of the hot path against the oracle — empty scene, ragged image sizes (tiles that stick out of
+the image), one bounce and the bounce cap, degenerate triangles, a scene of one triangle, the default downsample
+factor, the read_pixels tonemap, and protocol no-ops."""
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from loupiote_amd import testing as T
+from oracle import gltf_oracle as G, orc
+
+pytestmark = pytest.mark.gpu
+
+QUAD_POS = np.array([[-1, 0, -1, 0], [1, 0, -1, 0], [1, 0, 1, 0], [-1, 0, 1, 0]], np.float32)
+QUAD_IDX = np.array([0, 2, 1, 0, 3, 2], np.uint32)
+
+
+def _pair(build):
+    """the same scene through the C ABI and into the oracle's numpy Scene"""
+    ps, os_ = lp.Scene(), G.Scene()
+    build(ps), build(os_)
+    return ps, os_
+
+
+def _render_both(device, ps, os_, w, h, bounces, frames, probe=T.CORNELL_PROBE, eye=(0.0, 1.5, 4.0), direction=(0.0, -0.3, -1.0), seed=0):
+    view = T.look(eye, direction)
+    sg = lp.SceneGPU.new_from_scene(ps, device)
+    pr = lp.ProbeGPU(device, probe, probe.shape[1], probe.shape[0])
+    r = lp.Renderer(device, (w, h))
+    r.downsample_factor = 1.0
+    r.resize(device, sg, pr, (w, h))
+    r.set_max_bounces(bounces)
+    r.set_seed(seed)
+    r.set_vfov(T.VFOV)
+    r.reset_accumulation(); r.accumulate = True; r.reset_ray_counts()
+    for _ in range(frames):
+        r.raytrace(view)
+    img, px, c = r.read_radiance(), r.read_pixels(), r.ray_counts()
+    r.close(); pr.close(); sg.close()
+    sc = orc.OracleScene.from_scene(os_, probe=probe)
+    acc, oc = sc.render(w, h, view, T.VFOV, bounces, frames=frames, user_seed=seed, want_counters=True)
+    return img, px, c, orc.resolve(acc), orc.tonemap(acc), oc
+
+
+def _floor(s):
+    b = s.add_mesh(QUAD_POS * 3.0, None, None, QUAD_IDX)
+    m = s.add_material((0.7, 0.6, 0.5, 1.0), 0.6, 0.0)
+    s.add_instance(b, np.eye(4, dtype=np.float32).T.reshape(-1), m)
+    if isinstance(s, lp.Scene):
+        s.set_light(0, T.cornell_light())
+    else:
+        s.lights[0] = T.cornell_light()[0]
+
+
+def test_empty_scene_is_all_environment(device):
+    def build(s):
+        if isinstance(s, lp.Scene):
+            s.set_light(0, T.cornell_light())
+        else:
+            s.lights[0] = T.cornell_light()[0]
+    ps, os_ = _pair(build)
+    img, px, c, ref, ref_px, oc = _render_both(device, ps, os_, 70, 50, 3, 2, eye=(0, 0, 5), direction=(0, -0.2, -1))
+    assert img.tobytes() == ref.tobytes() and (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+    assert c.closest == 70 * 50 * 2 and c.shaded == 0          # every primary ray leaves; nothing is shaded
+    assert np.abs(px.astype(int) - ref_px.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (33, 9), (97, 61), (31, 7), (257, 3)])
+def test_ragged_sizes(device, w, h):
+    ps, os_ = _pair(_floor)
+    img, px, c, ref, ref_px, oc = _render_both(device, ps, os_, w, h, 4, 2)
+    assert img.shape == (h, w, 4) and img.tobytes() == ref.tobytes()
+    assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+    assert np.abs(px.astype(int) - ref_px.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("bounces", [1, 2, 17, 64])
+def test_bounce_counts(device, cornell_glb, bounces):
+    from oracle import harness
+    img, c = T.render_hip(device, cornell_glb, 64, 48, bounces, 1)
+    ref, oc = harness.render_oracle(cornell_glb, 64, 48, bounces, 1)
+    assert img.tobytes() == ref.tobytes() and (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+
+
+def test_degenerate_and_single_triangles(device):
+    def build(s):
+        _floor(s)
+        # zero-area triangles (collinear / coincident vertices) and one lone tilted triangle above the floor
+        deg = np.array([[0, 0.5, 0, 0], [1, 0.5, 0, 0], [2, 0.5, 0, 0], [0.3, 0.7, 0.3, 0], [0.3, 0.7, 0.3, 0], [0.3, 0.7, 0.3, 0]], np.float32)
+        b = s.add_mesh(deg, None, None, np.arange(6, dtype=np.uint32))
+        s.add_instance(b, np.eye(4, dtype=np.float32).T.reshape(-1), 0)
+        tri = np.array([[-0.8, 0.4, 0.2, 0], [0.9, 0.5, -0.1, 0], [0.1, 1.3, 0.0, 0]], np.float32)
+        b = s.add_mesh(tri, None, None, np.arange(3, dtype=np.uint32))
+        m = s.add_material((0.2, 0.8, 0.3, 1.0), 0.15, 1.0)
+        s.add_instance(b, np.eye(4, dtype=np.float32).T.reshape(-1), m)
+    ps, os_ = _pair(build)
+    img, px, c, ref, ref_px, oc = _render_both(device, ps, os_, 120, 80, 5, 3)
+    assert img.tobytes() == ref.tobytes() and (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+    assert np.all(np.isfinite(img))
+
+
+def test_protocol_noops_and_default_downsample(device, cornell_glb):
+    r = lp.Renderer(device, (200, 100))
+    assert r.get_size() == (100, 50)                                  # downsample_factor 0.5 (renderer.rs:225-226)
+    r.raytrace(T.look(T.CORNELL_EYE, T.CORNELL_DIR))                  # no resources yet: a no-op (:403-407)
+    assert not r.read_radiance().any()                                # nothing was traced
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    r.resize(device, sg, None, (200, 100))                            # probe None -> 1x1 default (:693-696)
+    assert r.get_size() == (100, 50)
+    r.raytrace(T.look(T.CORNELL_EYE, T.CORNELL_DIR))
+    assert r.read_radiance().shape == (50, 100, 4) and r.frame_state()[0] == 1   # accumulate is still false
+    r.accumulate = True
+    r.raytrace(T.look(T.CORNELL_EYE, T.CORNELL_DIR))
+    assert r.frame_state()[0] == 2
+    r.reset_accumulation()
+    assert r.frame_state() == (1, r.frame_state()[1]) and r.accumulate is False
+    r.close(); sg.close()
