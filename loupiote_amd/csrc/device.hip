@@ -40,6 +40,7 @@ struct lpt_scene_gpu {
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
     void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
+    void *obj_verts = nullptr, *obj_indices = nullptr, *bad_flag = nullptr;  // object-space meshes for device-side re-baking
     std::vector<uint32_t> inst_first, inst_count, level_start;
     std::vector<lpt_instance> instances;                                // as baked
     size_t n_entries = 0, n_vertices = 0, n_indices = 0;
@@ -286,7 +287,7 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     hipSetDevice(sg->dev->ordinal);
     hipStreamSynchronize(sg->dev->stream);
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->tri_material, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
-                    sg->tri_slot, sg->node_lo, sg->node_hi};
+                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
     return LPT_OK;
@@ -350,6 +351,9 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
         UP(node_lo, boxes)
         UP(node_hi, boxes)
     }
+    UP(obj_verts, scene->vertices)
+    UP(obj_indices, scene->indices)
+    { std::vector<uint32_t> zero(1, 0u); UP(bad_flag, zero) }
 #undef UP
     sg->inst_first = acc.inst_first; sg->inst_count = acc.inst_count; sg->level_start = acc.level_start;
     sg->instances = scene->instances;
@@ -407,35 +411,40 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
     HIP_TRY(hipSetDevice(sg->dev->ordinal));
     hipStream_t s = sg->dev->stream;
     uint32_t changed = 0;
-    std::vector<lpt_vertex> verts;
-    std::vector<WoopTri> woop;
     for (size_t i = 0; i < scene->instances.size(); ++i) {
         const lpt_instance &now = scene->instances[i];
         lpt_instance &was = sg->instances[i];
         if (now.blas_index != was.blas_index)
             return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: instance %zu refers to another mesh; upload again", i);
         if (memcmp(&now, &was, sizeof now) == 0) continue;
-        bake_instance(*scene, i, verts, woop);
-        if (verts.size() / 3 != sg->inst_count[i]) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: triangle count of instance %zu changed", i);
         const uint32_t first = sg->inst_first[i], n = sg->inst_count[i];
-        for (size_t k = 0; k < verts.size(); ++k)
-            for (int a = 0; a < 3; ++a)
-                if (!std::isfinite(verts[k].position[a])) return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in re-baked instance %zu", i);
         if (n) {
-            HIP_TRY(hipMemcpyAsync((lpt_vertex *)sg->tri_verts + 3u * (size_t)first, verts.data(), sizeof(lpt_vertex) * verts.size(), hipMemcpyHostToDevice, s));
-            void *tmp = nullptr;
-            HIP_TRY(hipMalloc(&tmp, sizeof(WoopTri) * n));
-            HIP_TRY(hipMemcpyAsync(tmp, woop.data(), sizeof(WoopTri) * n, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_scatter_woop, dim3(div_up(n, 256u)), dim3(256), 0, s, (const float4 *)tmp, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, first, n);
-            uint32_t mi = now.material_index;
-            if (mi >= scene->materials.size()) mi = 0;
-            std::vector<uint32_t> mats(n, mi);
-            HIP_TRY(hipMemcpyAsync((uint32_t *)sg->tri_material + first, mats.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s));  // host staging vectors are reused by the next instance
-            hipFree(tmp);
+            // re-bake on the device: the object-space mesh is resident, only the transform travels
+            const lpt_blas_entry &e = scene->entries[now.blas_index];
+            if (e.index_count / 3u != n) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: triangle count of instance %zu changed", i);
+            BakeArgs a;
+            memcpy(a.m, now.model_to_world, sizeof a.m);
+            const float *m = a.m;
+            const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
+            a.c[0] = a11 * a22 - a12 * a21; a.c[1] = a12 * a20 - a10 * a22; a.c[2] = a10 * a21 - a11 * a20;   // bvh.cpp bake_one
+            a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
+            a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
+            a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
+            a.material = now.material_index < scene->materials.size() ? now.material_index : 0u;
+            hipLaunchKernelGGL(k_bake_instance, dim3(div_up(n, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
+                               (float4 *)sg->tri_verts, (uint32_t *)sg->tri_material, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
         }
         was = now;
         ++changed;
+    }
+    if (changed) {
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, sg->bad_flag, sizeof bad, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad) {
+            HIP_TRY(hipMemsetAsync(sg->bad_flag, 0, sizeof bad, s));
+            return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in a re-baked instance");
+        }
     }
     if (changed && sg->stats.triangles) {
         for (size_t l = sg->level_start.size() - 1; l-- > 0;) {

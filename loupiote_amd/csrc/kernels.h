@@ -1145,6 +1145,65 @@ __global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, 
     nw[4] = make_uint4(pack4(4, 0), pack4(4, 1), pack4(5, 0), pack4(5, 1));
 }
 
+// ------------------------------------------------------------------ device-side baking of ONE instance (SPEC §2.5, §6)
+// The object-space mesh stays on the device; a moved instance is re-baked here with exactly the host's operations
+// (bvh.cpp bake_one / woop_from_triangle: fp32 transform with the parentheses shown there, cofactor normals,
+// Woop maps in binary64 rounded once) — -ffp-contract=off on both sides, so the results are bit-identical.
+struct BakeArgs {
+    float m[16];        // model_to_world, column-major
+    float c[9];         // cofactors of its 3x3 part, as bake_one computes them (row-major c00..c22)
+    uint32_t vertex_offset, index_offset, first_tri, n_tris, material;
+};
+
+__device__ __forceinline__ void woop_device(const float p0[3], const float p1[3], const float p2[3], float4 out[3]) {
+    const double ax = p0[0], ay = p0[1], az = p0[2];
+    const double e1x = (double)p1[0] - ax, e1y = (double)p1[1] - ay, e1z = (double)p1[2] - az;
+    const double e2x = (double)p2[0] - ax, e2y = (double)p2[1] - ay, e2z = (double)p2[2] - az;
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double det = nx * nx + ny * ny + nz * nz;
+    if (!(det > 0.0)) { out[0] = out[1] = out[2] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const double inv = 1.0 / det;
+    const double r0x = (e2y * nz - e2z * ny) * inv, r0y = (e2z * nx - e2x * nz) * inv, r0z = (e2x * ny - e2y * nx) * inv;
+    const double r1x = (ny * e1z - nz * e1y) * inv, r1y = (nz * e1x - nx * e1z) * inv, r1z = (nx * e1y - ny * e1x) * inv;
+    const double r2x = nx * inv, r2y = ny * inv, r2z = nz * inv;
+    out[0] = make_float4((float)r0x, (float)r0y, (float)r0z, (float)(-(r0x * ax + r0y * ay + r0z * az)));
+    out[1] = make_float4((float)r1x, (float)r1y, (float)r1z, (float)(-(r1x * ax + r1y * ay + r1z * az)));
+    out[2] = make_float4((float)r2x, (float)r2y, (float)r2z, (float)(-(r2x * ax + r2y * ay + r2z * az)));
+}
+
+__global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 *obj_verts /* 2 float4 per vertex */, const uint32_t *indices,
+                                                       float4 *tri_verts, uint32_t *tri_material, float4 *woop, const uint32_t *tri_slot, uint32_t *bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_tris) return;
+    const float *m = a.m;
+    float P[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t vi = a.vertex_offset + indices[a.index_offset + 3u * t + k];
+        const float4 vp = obj_verts[2u * (size_t)vi], vn = obj_verts[2u * (size_t)vi + 1];
+        const float x = vp.x, y = vp.y, z = vp.z;
+        float4 op;
+        op.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12];
+        op.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13];
+        op.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+        op.w = vp.w;
+        const float nx = vn.x, ny = vn.y, nz = vn.z;
+        float n0 = (a.c[0] * nx + a.c[1] * ny) + a.c[2] * nz, n1 = (a.c[3] * nx + a.c[4] * ny) + a.c[5] * nz, n2 = (a.c[6] * nx + a.c[7] * ny) + a.c[8] * nz;
+        const float l2 = (n0 * n0 + n1 * n1) + n2 * n2;
+        if (!(l2 > 0.f)) { n0 = n1 = n2 = 0.f; }
+        else { const float inv = 1.0f / sqrtf(l2); n0 *= inv; n1 *= inv; n2 *= inv; }
+        P[k][0] = op.x; P[k][1] = op.y; P[k][2] = op.z;
+        if (!(fabsf(op.x) <= 3.0e38f) || !(fabsf(op.y) <= 3.0e38f) || !(fabsf(op.z) <= 3.0e38f)) *bad = 1u;  // inf / NaN
+        float4 *dst = tri_verts + 6u * (size_t)(a.first_tri + t) + 2u * k;
+        dst[0] = op;
+        dst[1] = make_float4(n0, n1, n2, vn.w);
+    }
+    tri_material[a.first_tri + t] = a.material;
+    float4 w[3];
+    woop_device(P[0], P[1], P[2], w);
+    const uint32_t slot = tri_slot[a.first_tri + t];
+    woop[3u * (size_t)slot] = w[0]; woop[3u * (size_t)slot + 1] = w[1]; woop[3u * (size_t)slot + 2] = w[2];
+}
+
 // new Woop maps of a re-baked instance go to the leaf slots of its triangles
 __global__ __launch_bounds__(256) void k_scatter_woop(const float4 *src, float4 *woop, const uint32_t *tri_slot, uint32_t first_prim, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
