@@ -80,3 +80,35 @@ def test_gpu_built_helmet_frame_equals_host_built(device):
         imgs.append(r.read_radiance())
         r.close(); pr.close(); sg.close()
     assert imgs[0].tobytes() == imgs[1].tobytes()
+
+
+@pytest.mark.parametrize("kind", ["coincident", "coplanar", "n16", "n17", "random", "clusters"])
+def test_gpu_builder_degenerate_soups(device, kind):
+    """duplicate Morton codes, zero-extent axes and the smallest sizes the radix tree handles"""
+    rng = np.random.default_rng(21)
+    if kind == "coincident":
+        tri = np.repeat(rng.normal(0, 1, (1, 3, 3)), 300, axis=0)
+    elif kind == "coplanar":
+        tri = rng.uniform(-4, 4, (500, 1, 3)) + rng.normal(0, 0.3, (500, 3, 3)); tri[..., 1] = 0.5
+    elif kind in ("n16", "n17"):
+        n = int(kind[1:]); tri = rng.uniform(-2, 2, (n, 1, 3)) + rng.normal(0, 0.4, (n, 3, 3))
+    elif kind == "random":
+        tri = rng.uniform(-5, 5, (5000, 1, 3)) + rng.normal(0, 0.25, (5000, 3, 3))
+    else:
+        c = rng.uniform(-50, 50, (8, 3))
+        tri = c[rng.integers(0, 8, 4000)][:, None, :] + rng.normal(0, 0.02, (4000, 3, 3))
+    pos = np.zeros((tri.shape[0] * 3, 4), np.float32); pos[:, :3] = tri.reshape(-1, 3)
+    scene = lp.Scene()
+    b = scene.add_mesh(pos, None, None, None)
+    scene.add_instance(b, np.eye(4, dtype=np.float32).reshape(-1), 0)
+    host = lp.SceneGPU.new_from_scene(scene, device)
+    gpu = lp.SceneGPU.new_from_scene(scene, device, gpu_build=True)
+    assert gpu.stats().triangles == tri.shape[0] and gpu.stats().nodes >= 1
+    lo, hi = tri.min() - 1, tri.max() + 1
+    o, d = _rays(50000, (lo, lo, lo), (hi, hi, hi), 5)
+    # half of the rays aim at triangle centroids so that there are hits even in sparse soups
+    cen = tri.mean(axis=1)[rng.integers(0, tri.shape[0], 25000)]
+    v = cen - o[:25000, :3]; d[:25000, :3] = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-9)
+    a, bq = host.trace_closest(o, d), gpu.trace_closest(o, d)
+    assert a.tobytes() == bq.tobytes() and (a["prim"] != 0xFFFFFFFF).any()
+    host.close(); gpu.close()
