@@ -701,9 +701,11 @@ int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg, const l
 
 int lpt_renderer_resize(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe, uint32_t width, uint32_t height) {
     if (!r || !sg) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_resize: null");
+    const uint32_t nw = (uint32_t)((float)width * r->downsample), nh = (uint32_t)((float)height * r->downsample);
+    if (nw > 8192u || nh > 8192u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_resize: the path-traced size is limited to 8192 x 8192 (got %u x %u)", nw, nh);
     r->req_w = width; r->req_h = height;
-    r->w = (uint32_t)((float)width * r->downsample);
-    r->h = (uint32_t)((float)height * r->downsample);
+    r->w = nw;
+    r->h = nh;
     int st = alloc_frame_buffers(r);
     if (st != LPT_OK) return st;
     return lpt_renderer_set_resources(r, sg, probe);

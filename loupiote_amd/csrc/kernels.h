@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
         if (valid) {
             q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(vslot));
             q.d[idx] = make_float4(d.x, d.y, d.z, -1.0f);
-            q.T[idx] = make_float4(1.f, 1.f, 1.f, 0.f);
+            q.T[idx] = make_float4(1.f, 1.f, 1.f, __uint_as_float(x | (y << 13) | (sample << 26)));  // pixel + sample ride along: no divisions in k_shade
         }
     }
 }
@@ -602,7 +602,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_closest(DScene sc, const 
 }
 
 // ------------------------------------------------------------------ SPEC §9 textures / environment
-__device__ __forceinline__ int wrap_i(int x, int n) { int m = x % n; return m < 0 ? m + n : m; }
+__device__ __forceinline__ int wrap_i(int x, int n) {
+    if ((n & (n - 1)) == 0) return x & (n - 1);  // power-of-two sizes (the usual case): same value, no division
+    int m = x % n;
+    return m < 0 ? m + n : m;
+}
+// wrap(x + 1) from w = wrap(x): no second modulo
+__device__ __forceinline__ int wrap_next(int w, int n) { return w + 1 == n ? 0 : w + 1; }
 
 // `lut`: the 256-entry sRGB decode table, staged in LDS by the caller (12 table reads per albedo lookup)
 __device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *lut, uint32_t image, float u, float v, bool srgb) {
@@ -611,8 +617,8 @@ __device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *
     float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
     float x0f = floorf(fx), y0f = floorf(fy);
     float tx = fx - x0f, ty = fy - y0f;
-    int x0 = wrap_i((int)x0f, W), x1 = wrap_i((int)x0f + 1, W);
-    int y0 = wrap_i((int)y0f, H), y1 = wrap_i((int)y0f + 1, H);
+    int x0 = wrap_i((int)x0f, W), x1 = wrap_next(x0, W);
+    int y0 = wrap_i((int)y0f, H), y1 = wrap_next(y0, H);
     const uchar4 *base = reinterpret_cast<const uchar4 *>(sc.texels) + im.offset;
     const uchar4 p00 = base[(size_t)y0 * W + x0], p10 = base[(size_t)y0 * W + x1];
     const uchar4 p01 = base[(size_t)y1 * W + x0], p11 = base[(size_t)y1 * W + x1];
@@ -651,7 +657,7 @@ __device__ __forceinline__ f3 env_lookup(const DProbe &pr, f3 d) {
     float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
     float x0f = floorf(fx), y0f = floorf(fy);
     float tx = fx - x0f, ty = fy - y0f;
-    int x0 = wrap_i((int)x0f, W), x1 = wrap_i((int)x0f + 1, W);
+    int x0 = wrap_i((int)x0f, W), x1 = wrap_next(x0, W);
     int y0 = (int)y0f, y1 = (int)y0f + 1;
     y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
     y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
@@ -734,6 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
         if (i < count) {
             const float4 o4 = qin.o[i], d4 = qin.d[i], T4 = qin.T[i], h4 = hits[i];
             const uint32_t slot = __float_as_uint(o4.w);
+            const uint32_t pxy = __float_as_uint(T4.w);  // x | y << 13 | sample << 26 (k_raygen)
             const f3 d = mk3(d4.x, d4.y, d4.z);
             const f3 T = mk3(T4.x, T4.y, T4.z);
             const float pdf_prev = d4.w;
@@ -803,9 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     const f3 V = neg(d);
                     const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
                     const float pspec = spec_probability(sf, NoV);
-                    uint32_t x = 0, y = 0;
-                    const uint32_t sample = slot / p.n_slots;
-                    slot_to_pixel(p, slot - sample * p.n_slots, x, y);
+                    const uint32_t x = pxy & 0x1FFFu, y = (pxy >> 13) & 0x1FFFu, sample = pxy >> 26;
                     const uint32_t pixel = y * p.width + x;
                     const uint32_t seed_counter = seed_base + sample * p.max_bounces;
                     Rng rg = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_SHADE);
@@ -862,15 +867,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                                 want_next = true;
                                 no4 = make_float4(Po.x, Po.y, Po.z, o4.w);
                                 nd4 = make_float4(Ln.x, Ln.y, Ln.z, pdf);
-                                nT4 = make_float4(Tn.x, Tn.y, Tn.z, 0.f);
+                                nT4 = make_float4(Tn.x, Tn.y, Tn.z, T4.w);
                             }
                         }
                     }
                 }
             }
             if (GBUF && bounce == 0) {
-                uint32_t gx = 0, gy = 0;
-                slot_to_pixel(p, slot % p.n_slots, gx, gy);
+                const uint32_t gx = pxy & 0x1FFFu, gy = (pxy >> 13) & 0x1FFFu;
                 const size_t px = (size_t)gy * p.width + gx;
                 gb.gbuf[px] = make_uint4(prim, __float_as_uint(h4.x), oct_encode(g_n), pack_albedo(g_alb));
                 float mu = 0.0f, mv = 0.0f, cu, cv, pu, pv;
