@@ -35,7 +35,7 @@ struct lpt_device {
 struct lpt_scene_gpu {
     lpt_device *dev = nullptr;
     DScene d{};
-    void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr, *tri_material = nullptr;
+    void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr;
     void *materials = nullptr, *lights = nullptr, *texels = nullptr, *images = nullptr, *srgb_lut = nullptr;
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
@@ -286,7 +286,7 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     if (!sg) return LPT_OK;
     hipSetDevice(sg->dev->ordinal);
     hipStreamSynchronize(sg->dev->stream);
-    void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->tri_material, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
+    void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
                     sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
@@ -321,8 +321,16 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
         UP(woop, acc.woop)
         UP(leaf_prim, acc.leaf_prim)
     }
-    UP(tri_verts, acc.tri_verts)
-    UP(tri_material, acc.tri_material)
+    {   // shading records (kernels.h DScene::tri_verts): three vertices + the material, 128 B per triangle
+        struct TriRec { float4 v[kTriRec]; };
+        static_assert(sizeof(TriRec) == 128 && sizeof(lpt_vertex) * 3 == 96 && sizeof(lpt_material) == 32, "shading record layout");
+        std::vector<TriRec> recs(acc.tri_material.size());
+        for (size_t t = 0; t < recs.size(); ++t) {
+            memcpy(recs[t].v, &acc.tri_verts[3 * t], 96);
+            memcpy(&recs[t].v[6], &scene->materials[acc.tri_material[t] < scene->materials.size() ? acc.tri_material[t] : 0], 32);
+        }
+        UP(tri_verts, recs)
+    }
     UP(materials, scene->materials)
     UP(lights, scene->lights)
     std::vector<DImage> descs;
@@ -368,7 +376,6 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     d.woop = (const float4 *)sg->woop;
     d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     d.tri_verts = (const float4 *)sg->tri_verts;
-    d.tri_material = (const uint32_t *)sg->tri_material;
     d.materials = (const lpt_material *)sg->materials;
     d.lights = (const lpt_light *)sg->lights;
     d.texels = (const uint8_t *)sg->texels;
@@ -430,9 +437,9 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
             a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
             a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
             a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
-            a.material = now.material_index < scene->materials.size() ? now.material_index : 0u;
+            memcpy(a.mat, &scene->materials[now.material_index < scene->materials.size() ? now.material_index : 0u], 32);
             hipLaunchKernelGGL(k_bake_instance, dim3(div_up(n, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
-                               (float4 *)sg->tri_verts, (uint32_t *)sg->tri_material, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
+                               (float4 *)sg->tri_verts, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
         }
         was = now;
         ++changed;

@@ -30,14 +30,17 @@ struct DNode8 {
 };
 
 struct DImage { uint32_t offset, width, height, pad; };
+constexpr uint32_t kTriRec = 8;
 
 struct DScene {
     const DNode8 *nodes;
     uint32_t stack_entries;      // wide-tree depth + 1: per-lane traversal stack capacity (uint2 entries)
     const float4 *woop;          // 3 per leaf slot
     const uint32_t *leaf_prim;   // leaf slot -> baked triangle id
-    const float4 *tri_verts;     // 6 per baked triangle: (pos,u)(nrm,v) x3
-    const uint32_t *tri_material;
+    // shading record: kTriRec float4 = 128 B per baked triangle, one cache line: (pos,u)(nrm,v) x3 and the triangle's
+    // material verbatim (colour | roughness, reflectivity, albedo / mra texture).  One fetch instead of a 96-B run that
+    // straddles two lines half of the time + the material index + the material (k_shade is bound by L2-miss traffic)
+    const float4 *tri_verts;
     const lpt_material *materials;
     const lpt_light *lights;
     const uint8_t *texels;       // RGBA8, all images back to back
@@ -772,8 +775,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                 Lsum[slot] = L;
             } else {
                 const float hu = h4.y, hv = h4.z;
-                const float4 *tv = sc.tri_verts + 6u * (size_t)prim;
+                const float4 *tv = sc.tri_verts + kTriRec * (size_t)prim;
                 const float4 P0 = tv[0], N0 = tv[1], P1 = tv[2], N1 = tv[3], P2 = tv[4], N2 = tv[5];
+                const float4 mc = tv[6], mp = tv[7];
                 float bw = (1.0f - hu) - hv;
                 const f3 p0 = mk3(P0.x, P0.y, P0.z), p1 = mk3(P1.x, P1.y, P1.z), p2 = mk3(P2.x, P2.y, P2.z);
                 f3 P = mk3((p0.x * bw + p1.x * hu) + p2.x * hv, (p0.y * bw + p1.y * hu) + p2.y * hv, (p0.z * bw + p1.z * hu) + p2.z * hv);
@@ -789,10 +793,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     if (dot(Ns, Ng) < 0.0f) Ns = neg(Ns);
                     float tu = (P0.w * bw + P1.w * hu) + P2.w * hv;
                     float tvv = (N0.w * bw + N1.w * hu) + N2.w * hv;
-                    uint32_t mi = sc.tri_material[prim];
-                    if (mi >= sc.n_materials) mi = 0;
-                    const float4 *M4 = reinterpret_cast<const float4 *>(sc.materials + mi);
-                    const float4 mc = M4[0], mp = M4[1];
                     f3 base = mk3(mc.x, mc.y, mc.z);
                     float rough = mp.x, metal = mp.y;
                     const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_query_occluded(DScene sc, const
 // (moved) triangles, one breadth-first level per launch, deepest level first.  Mirrors the quantisation of
 // the host builder (bvh.cpp): padded triangle boxes, power-of-two grid step >= extent/255, floor / ceil.
 __device__ __forceinline__ void refit_grow_tri(const DScene &sc, uint32_t prim, float lo[3], float hi[3]) {
-    const float4 *tv = sc.tri_verts + 6u * (size_t)prim;
+    const float4 *tv = sc.tri_verts + kTriRec * (size_t)prim;
     const float4 P0 = tv[0], P1 = tv[2], P2 = tv[4];
     const float px[3] = {P0.x, P1.x, P2.x}, py[3] = {P0.y, P1.y, P2.y}, pz[3] = {P0.z, P1.z, P2.z};
     const float *pp[3] = {px, py, pz};
@@ -1156,7 +1156,8 @@ __global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, 
 struct BakeArgs {
     float m[16];        // model_to_world, column-major
     float c[9];         // cofactors of its 3x3 part, as bake_one computes them (row-major c00..c22)
-    uint32_t vertex_offset, index_offset, first_tri, n_tris, material;
+    uint32_t vertex_offset, index_offset, first_tri, n_tris;
+    float4 mat[2];      // the instance's material (lpt_material verbatim), copied into every shading record
 };
 
 __device__ __forceinline__ void woop_device(const float p0[3], const float p1[3], const float p2[3], float4 out[3]) {
@@ -1176,7 +1177,7 @@ __device__ __forceinline__ void woop_device(const float p0[3], const float p1[3]
 }
 
 __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 *obj_verts /* 2 float4 per vertex */, const uint32_t *indices,
-                                                       float4 *tri_verts, uint32_t *tri_material, float4 *woop, const uint32_t *tri_slot, uint32_t *bad) {
+                                                       float4 *tri_verts, float4 *woop, const uint32_t *tri_slot, uint32_t *bad) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_tris) return;
     const float *m = a.m;
@@ -1197,11 +1198,12 @@ __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 
         else { const float inv = 1.0f / sqrtf(l2); n0 *= inv; n1 *= inv; n2 *= inv; }
         P[k][0] = op.x; P[k][1] = op.y; P[k][2] = op.z;
         if (!(fabsf(op.x) <= 3.0e38f) || !(fabsf(op.y) <= 3.0e38f) || !(fabsf(op.z) <= 3.0e38f)) *bad = 1u;  // inf / NaN
-        float4 *dst = tri_verts + 6u * (size_t)(a.first_tri + t) + 2u * k;
+        float4 *dst = tri_verts + kTriRec * (size_t)(a.first_tri + t) + 2u * k;
         dst[0] = op;
         dst[1] = make_float4(n0, n1, n2, vn.w);
     }
-    tri_material[a.first_tri + t] = a.material;
+    tri_verts[kTriRec * (size_t)(a.first_tri + t) + 6u] = a.mat[0];
+    tri_verts[kTriRec * (size_t)(a.first_tri + t) + 7u] = a.mat[1];
     float4 w[3];
     woop_device(P[0], P[1], P[2], w);
     const uint32_t slot = tri_slot[a.first_tri + t];
