@@ -336,11 +336,19 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     std::vector<DImage> descs;
     std::vector<uint8_t> texels;
     for (const Image &im : scene->images) {
+        // texels are stored in 8x4-texel tiles of 128 B (one cache line): the 2x2 bilinear footprint then touches
+        // 1.4 lines on average instead of 2 (k_shade is bound by L2-miss traffic); `pad` = tiles per row
         DImage di;
         di.offset = (uint32_t)(texels.size() / 4);
-        di.width = im.width; di.height = im.height; di.pad = 0;
+        di.width = im.width; di.height = im.height;
+        const uint32_t tx = (im.width + 7u) / 8u, ty = (im.height + 3u) / 4u;
+        di.pad = tx;
         descs.push_back(di);
-        texels.insert(texels.end(), im.rgba8.begin(), im.rgba8.end());
+        const size_t base = texels.size();
+        texels.resize(base + (size_t)tx * ty * 128u, 0);
+        for (uint32_t y = 0; y < im.height; ++y)
+            for (uint32_t x = 0; x < im.width; ++x)
+                memcpy(&texels[base + 4u * (((size_t)(y >> 2) * tx + (x >> 3)) * 32u + (y & 3u) * 8u + (x & 7u))], &im.rgba8[4u * ((size_t)y * im.width + x)], 4);
     }
     UP(images, descs)
     UP(texels, texels)

@@ -29,7 +29,7 @@ struct DNode8 {
     uint4 n4;  // qhi_y[0..3], qhi_y[4..7], qhi_z[0..3], qhi_z[4..7]
 };
 
-struct DImage { uint32_t offset, width, height, pad; };
+struct DImage { uint32_t offset, width, height, pad; };  // pad = 8x4-texel tiles per row (texels are tiled, device.hip)
 constexpr uint32_t kTriRec = 8;
 
 struct DScene {
@@ -623,8 +623,11 @@ __device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *
     int x0 = wrap_i((int)x0f, W), x1 = wrap_next(x0, W);
     int y0 = wrap_i((int)y0f, H), y1 = wrap_next(y0, H);
     const uchar4 *base = reinterpret_cast<const uchar4 *>(sc.texels) + im.offset;
-    const uchar4 p00 = base[(size_t)y0 * W + x0], p10 = base[(size_t)y0 * W + x1];
-    const uchar4 p01 = base[(size_t)y1 * W + x0], p11 = base[(size_t)y1 * W + x1];
+    const uint32_t tiles_x = im.pad;
+    const uint32_t r0 = ((uint32_t)y0 >> 2) * tiles_x * 32u + ((uint32_t)y0 & 3u) * 8u, r1 = ((uint32_t)y1 >> 2) * tiles_x * 32u + ((uint32_t)y1 & 3u) * 8u;
+    const uint32_t c0 = ((uint32_t)x0 >> 3) * 32u + ((uint32_t)x0 & 7u), c1 = ((uint32_t)x1 >> 3) * 32u + ((uint32_t)x1 & 7u);
+    const uchar4 p00 = base[r0 + c0], p10 = base[r0 + c1];
+    const uchar4 p01 = base[r1 + c0], p11 = base[r1 + c1];
     const uint8_t a00[4] = {p00.x, p00.y, p00.z, p00.w}, a10[4] = {p10.x, p10.y, p10.z, p10.w};
     const uint8_t a01[4] = {p01.x, p01.y, p01.z, p01.w}, a11[4] = {p11.x, p11.y, p11.z, p11.w};
     float out[4];
