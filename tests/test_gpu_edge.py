@@ -116,3 +116,38 @@ def test_protocol_noops_and_default_downsample(device, cornell_glb):
     r.reset_accumulation()
     assert r.frame_state() == (1, r.frame_state()[1]) and r.accumulate is False
     r.close(); sg.close()
+
+
+def test_lifecycle_does_not_leak_device_memory(device, cornell_glb):
+    """create / resize / render / destroy in a loop: free device memory returns to where it started"""
+    import torch
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+
+    def cycle(k):
+        sg = lp.SceneGPU.new_from_scene(scene, device, gpu_build=bool(k & 1))
+        pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+        r = lp.Renderer(device, (64, 64))
+        r.downsample_factor = 1.0
+        for (w, h) in [(64, 48), (200 + 8 * (k % 4), 120), (33, 9)]:
+            r.resize(device, sg, pr, (w, h))
+            r.accumulate = True
+            r.raytrace_n(view, 1 + (k % 3))
+            if k % 4 == 0:
+                r.set_blit_mode(lp.BlitMode.DenoisedPathrace)
+                r.raytrace(view)
+                r.set_blit_mode(lp.BlitMode.Pahtrace)
+            assert r.read_pixels().shape == (h, w, 4)
+        sg.update_instances(scene)
+        r.close(); pr.close(); sg.close()
+
+    for k in range(12):                                  # every variant once: the runtime's own pools are warm
+        cycle(k)
+    device.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for k in range(24):
+        cycle(k)
+    device.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)      # allocator slack only, no per-cycle growth
