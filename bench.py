@@ -7,8 +7,10 @@ Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponz
   start pose.  One "step" = one such frame: reset_accumulation(); accumulate=true;
   4 x Renderer::raytrace(view) — issued as lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
   Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
-  Consecutive steps alternate between two renderers with their own HIP streams (--pipeline 2), so the tail of
-  frame k (and its collective) overlaps the head of frame k+1; every step is still one complete frame.
+  Consecutive steps rotate over three renderers with their own HIP streams (--pipeline 3: three frames in flight,
+  triple buffering), so the tail of frame k (and its collective) overlaps the heads of the next frames; every step is
+  still one complete frame.  GPU_MAX_HW_QUEUES is raised to 8 (ROCm default 4, of which the streams here got two):
+  with fewer hardware queues than streams the frames serialise again.
   N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
   N grows ("strong" scaling of one frame).
 
@@ -23,6 +25,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime at initialisation: one hardware queue per stream
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -77,7 +80,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, reduce) even with one rank")
     ap.add_argument("--exchange", choices=["reduce", "gather"], default="reduce",
                     help="frame exchange for N>1: dense RCCL reduce of the accumulation buffer (north star) or a gather of owned tiles only")
-    ap.add_argument("--pipeline", type=int, default=2, help="renderers (each with its own HIP stream) that take consecutive steps in turn")
+    ap.add_argument("--pipeline", type=int, default=3, help="renderers (each with its own HIP stream) that take consecutive steps in turn")
     ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
