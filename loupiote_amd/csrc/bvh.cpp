@@ -276,14 +276,6 @@ Box padded_box(const lpt_vertex *v) {
 
 }  // namespace
 
-void bake_instance(const lpt_scene &scene, size_t instance, std::vector<lpt_vertex> &verts, std::vector<WoopTri> &woop) {
-    verts.clear();
-    woop.clear();
-    bake_one(scene, instance, verts);
-    woop.resize(verts.size() / 3);
-    for (size_t t = 0; t < woop.size(); ++t) woop_from_triangle(verts[3 * t].position, verts[3 * t + 1].position, verts[3 * t + 2].position, woop[t]);
-}
-
 int bake_only(const lpt_scene &scene, Accel &out) {
     bake(scene, out);
     const size_t n = out.tri_material.size();

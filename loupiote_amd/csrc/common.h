@@ -70,8 +70,6 @@ struct Accel {
 int bake_and_build(const lpt_scene &scene, Accel &out);
 // baking only (for the GPU builder): tri_verts, tri_material, inst_first/count and the Woop maps in PRIM order
 int bake_only(const lpt_scene &scene, Accel &out);
-// world-space vertices (3 per triangle) and Woop maps of ONE instance, exactly as bake_and_build produces them
-void bake_instance(const lpt_scene &scene, size_t instance, std::vector<lpt_vertex> &verts, std::vector<WoopTri> &woop);
 void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3], WoopTri &w);
 
 // png.cpp

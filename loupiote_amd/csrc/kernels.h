@@ -1213,14 +1213,4 @@ __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 
     woop[3u * (size_t)slot] = w[0]; woop[3u * (size_t)slot + 1] = w[1]; woop[3u * (size_t)slot + 2] = w[2];
 }
 
-// new Woop maps of a re-baked instance go to the leaf slots of its triangles
-__global__ __launch_bounds__(256) void k_scatter_woop(const float4 *src, float4 *woop, const uint32_t *tri_slot, uint32_t first_prim, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = tri_slot[first_prim + i];
-    woop[3u * (size_t)slot] = src[3u * (size_t)i];
-    woop[3u * (size_t)slot + 1] = src[3u * (size_t)i + 1];
-    woop[3u * (size_t)slot + 2] = src[3u * (size_t)i + 2];
-}
-
 }  // namespace lptd
