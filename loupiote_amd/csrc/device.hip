@@ -76,6 +76,7 @@ struct lpt_renderer {
     // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
     int refill = 44;
     bool merge_trace = true;
+    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
     uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
@@ -656,6 +657,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
         hipError_t se = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     }
+    if (const char *ev = getenv("LPT_SHADE_BLOCKS_PER_CU")) r->shade_blocks_per_cu = (uint32_t)std::max(1, std::min(64, atoi(ev)));
     if (const char *ev = getenv("LPT_MERGE_TRACE")) r->merge_trace = atoi(ev) != 0;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
@@ -953,6 +955,7 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
+        const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
         // persistent waves: about 4 primary rays per lane, between 8 and 32 waves per CU.  A small frame (a tile shard
         // of a multi-GPU frame) runs faster on fewer, longer-lived waves — measured on a 1/8 shard: 16 waves/CU 2.11 ms,
         // 32 waves/CU 2.32 ms — while the full frame wants all 32 (12.04 vs 12.54 ms at 16).
@@ -997,9 +1000,9 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
             }
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
-                hipLaunchKernelGGL(k_shade<true>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3(stream_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
             stage_end(r);
             if (r->merge_trace) {
                 trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);
