@@ -262,6 +262,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": i_launches, "frames_in_flight": P,
                          "solo": {"achieved": solo, "frac": solo / HBM_PEAK_GBS, "avg_launch_ms": s_avg, "launches": s_launches}, "rays_per_launch": rays_per_launch,
+                         "note": "avg_launch_ms / achieved / frac: HIP events around every k_trace launch of the timed region; with several frames in flight they include the time a launch shares or waits for the CUs (rocprofv3 serialises kernels, so its per-kernel average matches `solo`, the same kernel with nothing co-running)",
                          "bytes_per_launch": bytes_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
