@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the other BASELINE.json configs on one MI355X (they are parity cases, not the bench line).
+usage (GPU box): PYTHONPATH=. python tools/configs_timing.py   -> one JSON object per config"""
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch  # noqa: F401,E402  (before libloupiote_hip.so: see INTEGRATION.md §7)
+
+import loupiote_amd as lp  # noqa: E402
+from loupiote_amd import scenes, testing as T  # noqa: E402
+
+
+def measure(dev, name, scene, probe, cam, w, h, spp, depth, frames=12, warm=3, mode=lp.BlitMode.Pahtrace, pipeline=3):
+    sg = lp.SceneGPU.new_from_scene(scene, dev)
+    pr = lp.ProbeGPU(dev, probe, probe.shape[1], probe.shape[0])
+    view = T.look(*cam)
+    rs = []
+    for _ in range(pipeline):
+        r = lp.Renderer(dev, (w, h))
+        r.downsample_factor = 1.0
+        r.resize(dev, sg, pr, (w, h))
+        r.set_max_bounces(depth)
+        r.set_vfov(T.VFOV)
+        r.set_blit_mode(mode)
+        rs.append(r)
+
+    def step(k):
+        r = rs[k % pipeline]
+        r.reset_accumulation()
+        r.accumulate = True
+        r.raytrace_n(view, spp)
+
+    for k in range(warm):
+        step(k)
+    for r in rs:
+        r.synchronize(); r.reset_ray_counts()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        step(k)
+    for r in rs:
+        r.synchronize()
+    dt = time.perf_counter() - t0
+    rays = sum(r.ray_counts().closest + r.ray_counts().shadow for r in rs)
+    out = {"config": name, "size": [w, h], "spp": spp, "depth": depth, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6,
+           "triangles": sg.stats().triangles, "frames_in_flight": pipeline}
+    for r in rs:
+        r.close()
+    pr.close(); sg.close()
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    dev = lp.Device(0)
+    glb = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "cornell-box.glb"), "rb").read()
+    s = lp.Scene(); lp.loaders.load_gltf(glb, s); s.set_light(0, T.cornell_light())
+    measure(dev, "2: cornell-box 1024x1024 4spp depth 8", s, T.CORNELL_PROBE, (T.CORNELL_EYE, T.CORNELL_DIR), 1024, 1024, 4, 8)
+    d = scenes.synthetic_helmet()
+    measure(dev, "3: synthetic_helmet (DamagedHelmet stand-in) + sky probe 1920x1080 8spp depth 8", scenes.to_product(d), d["probe"],
+            (d["camera"]["origin"], d["camera"]["direction"]), 1920, 1080, 8, 8)
+    d = scenes.synthetic_atrium()
+    sc = scenes.to_product(d)
+    cam = (d["camera"]["origin"], d["camera"]["direction"])
+    measure(dev, "4: synthetic_atrium 1920x1080 4spp depth 8 (the bench line)", sc, d["probe"], cam, 1920, 1080, 4, 8)
+    measure(dev, "5a: synthetic_atrium 3840x2160 64spp progressive (8 x raytrace_n(8)) depth 8", sc, d["probe"], cam, 3840, 2160, 8, 8, frames=8, warm=2, pipeline=2)
+    measure(dev, "5b: synthetic_atrium 3840x2160 temporal accumulate, 1 spp per frame, depth 8", sc, d["probe"], cam, 3840, 2160, 1, 8, frames=16, warm=3,
+            mode=lp.BlitMode.Temporal, pipeline=1)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
