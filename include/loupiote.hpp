@@ -90,6 +90,8 @@ class SceneGPU {  // scene.rs:56-64,151-188
     lpt_scene_gpu *handle() const { return h_; }
     lpt_accel_stats stats() const { lpt_accel_stats s; check(lpt_scene_gpu_stats(h_, &s)); return s; }
     /// re-bake the instances whose transform changed and refit the BVH on the GPU (standalone/src/lib.rs:118-121)
+    /// re-bake every instance and rebuild the BVH on the GPU (for edits too large for a refit)
+    void rebuild(const Scene &scene) { check(lpt_scene_gpu_rebuild(h_, scene.handle())); }
     uint32_t update_instances(const Scene &scene) { uint32_t n = 0; check(lpt_scene_gpu_update_instances(h_, scene.handle(), &n)); return n; }
 
    private:

@@ -259,6 +259,10 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg);
  * (LPT_ERR_INVALID_ARG otherwise: upload again).  Renderers bound to this lpt_scene_gpu keep working; call
  * lpt_renderer_reset_accumulation as after any scene change.  out_rebaked may be NULL. */
 int lpt_scene_gpu_update_instances(lpt_scene_gpu *scene_gpu, const lpt_scene *scene, uint32_t *out_rebaked);
+/* new: like lpt_scene_gpu_update_instances, but every instance is re-baked and the tree is REBUILT on the GPU
+ * (Morton radix tree, as LPT_ACCEL_BUILD_GPU_LBVH) instead of refitted — for edits that move things far, where a refit
+ * keeps a topology that no longer fits.  Renderers bound to this lpt_scene_gpu keep working. */
+int lpt_scene_gpu_rebuild(lpt_scene_gpu *scene_gpu, const lpt_scene *scene);
 int lpt_scene_gpu_stats(const lpt_scene_gpu *sg, lpt_accel_stats *out);
 
 /* replaces: ProbeGPU::new(device, queue, data, width, height)

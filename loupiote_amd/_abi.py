@@ -90,6 +90,7 @@ SIGNATURES = {
     "lpt_scene_upload_ex": (_i, [_vp, _vp, _u32, _pvp]),
     "lpt_scene_gpu_destroy": (_i, [_vp]),
     "lpt_scene_gpu_stats": (_i, [_vp, C.POINTER(AccelStats)]),
+    "lpt_scene_gpu_rebuild": (_i, [_vp, _vp]),
     "lpt_scene_gpu_update_instances": (_i, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "lpt_probe_upload": (_i, [_vp, _vp, _u32, _u32, _pvp]),
     "lpt_probe_destroy": (_i, [_vp]),

@@ -214,6 +214,10 @@ class SceneGPU:
         _check(A.lib().lpt_scene_gpu_update_instances(self._h, scene._h, C.byref(n)))
         return int(n.value)
 
+    def rebuild(self, scene):
+        """re-bake every instance and rebuild the BVH on the GPU (for edits too large for a refit)"""
+        _check(A.lib().lpt_scene_gpu_rebuild(self._h, scene._h))
+
     def trace_closest(self, origins, dirs):
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(dirs, np.float32)

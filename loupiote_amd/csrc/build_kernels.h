@@ -230,6 +230,24 @@ __global__ __launch_bounds__(64) void k_lbvh_emit(LbvhTree T, LbvhLevel L, const
                        meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24));
 }
 
+// scene bounds of the baked triangles (positions of the shading records): per-block reduction, then ordered-int atomics
+__device__ __forceinline__ int lbvh_f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }  // order-preserving
+__global__ __launch_bounds__(256) void k_lbvh_bounds(DScene sc, uint32_t n, int *bounds /* lo xyz, hi xyz as ordered ints */) {
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const float4 *tv = sc.tri_verts + kTriRec * (size_t)t;
+        for (int k = 0; k < 3; ++k) {
+            const float4 P = tv[2 * k];
+            lo[0] = fminf(lo[0], P.x); lo[1] = fminf(lo[1], P.y); lo[2] = fminf(lo[2], P.z);
+            hi[0] = fmaxf(hi[0], P.x); hi[1] = fmaxf(hi[1], P.y); hi[2] = fmaxf(hi[2], P.z);
+        }
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = fminf(lo[a], __shfl_down(lo[a], off)); hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off)); }
+    if ((threadIdx.x & 63u) == 0)
+        for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], lbvh_f2o(lo[a])); atomicMax(&bounds[3 + a], lbvh_f2o(hi[a])); }
+}
+
 // prim-ordered Woop maps -> leaf order
 __global__ __launch_bounds__(256) void k_lbvh_scatter_woop(const float4 *src, float4 *woop, const uint32_t *tri_slot, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -41,6 +41,8 @@ struct lpt_scene_gpu {
     // refit bookkeeping (lpt_scene_gpu_update_instances)
     void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
     void *obj_verts = nullptr, *obj_indices = nullptr, *bad_flag = nullptr;  // object-space meshes for device-side re-baking
+    void *arena = nullptr;                                                    // scratch of the GPU builder, kept for rebuilds
+    size_t arena_bytes = 0;
     std::vector<uint32_t> inst_first, inst_count, level_start;
     std::vector<lpt_instance> instances;                                // as baked
     size_t n_entries = 0, n_vertices = 0, n_indices = 0;
@@ -129,18 +131,43 @@ static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
 // ---------------------------------------------------------------------------- GPU builder (build_kernels.h)
 // Fills sg->nodes / woop / leaf_prim / tri_slot / node_lo / node_hi / level_start from the baked triangles that are
 // already on the device (sg->d.tri_verts).  `woop_prim` = the Woop maps in prim order (host, SPEC §6).
-static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
-    const uint32_t n = (uint32_t)acc.tri_material.size();
+// `host_woop`: the Woop maps in prim order on the host (upload path) or nullptr when `dev_woop` (device, prim order) is given.
+static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, const float4 *dev_woop, hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
-    float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (const lpt_vertex &v : acc.tri_verts)
-        for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], v.position[a]); bhi[a] = std::max(bhi[a], v.position[a]); }
+    float blo[3], bhi[3];
+    {   // scene bounds from the baked triangles on the device
+        int *db = nullptr, hb[6];
+        const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        HIP_TRY(hipMalloc(&db, sizeof init));
+        HIP_TRY(hipMemcpyAsync(db, init, sizeof init, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>(div_up(n, 256u), 1024u)), dim3(256), 0, s, sg->d, n, db);
+        HIP_TRY(hipMemcpyAsync(hb, db, sizeof hb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        hipFree(db);
+        for (int a = 0; a < 6; ++a) { const int o = hb[a] >= 0 ? hb[a] : hb[a] ^ 0x7FFFFFFF; float f; memcpy(&f, &o, 4); (a < 3 ? blo[a] : bhi[a - 3]) = f; }
+    }
     float binv[3];
     for (int a = 0; a < 3; ++a) binv[a] = bhi[a] > blo[a] ? 1.0f / (bhi[a] - blo[a]) : 0.0f;
 
-    std::vector<void *> tmp;  // scratch, freed on every exit
-    auto scratch = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr; tmp.push_back(p); return p; };
-    auto done = [&](int st) { hipStreamSynchronize(s); for (void *p : tmp) hipFree(p); return st; };
+    // scratch: one arena per scene, kept for the next rebuild (about 330 B per triangle); a bump allocator over it
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 30, s);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, s);
+    const size_t need = (size_t)n * 336u + std::max(sort_bytes, scan_bytes) + 64u * 256u;
+    if (sg->arena_bytes < need) {
+        if (sg->arena) hipFree(sg->arena);
+        sg->arena = nullptr; sg->arena_bytes = 0;
+        if (hipMalloc(&sg->arena, need) != hipSuccess) return fail(LPT_ERR_HIP, "GPU BVH build: out of device memory (%zu bytes of scratch)", need);
+        sg->arena_bytes = need;
+    }
+    size_t arena_used = 0;
+    auto scratch = [&](size_t bytes) -> void * {
+        const size_t at = (arena_used + 255u) & ~(size_t)255u;
+        if (at + bytes > sg->arena_bytes) return nullptr;
+        arena_used = at + bytes;
+        return (char *)sg->arena + at;
+    };
+    auto done = [&](int st) { hipStreamSynchronize(s); return st; };
 #define LB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: %s", hipGetErrorString(e_))); } while (0)
 #define SCR(type, name, count) type *name = (type *)scratch(sizeof(type) * (size_t)(count)); if (!name) return done(fail(LPT_ERR_HIP, "GPU BVH build: out of device memory"));
     SCR(uint32_t, keys, n) SCR(uint32_t, vals, n) SCR(uint32_t, keys_s, n) SCR(uint32_t, vals_s, n)
@@ -151,10 +178,6 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     T.lo = t_lo; T.hi = t_hi; T.tri_lo = t_tlo; T.tri_hi = t_thi; T.flag = t_flag; T.sorted_tri = vals_s; T.keys = keys_s; T.n = n;
     const uint32_t b256 = div_up(n, 256u);
     hipLaunchKernelGGL(k_lbvh_morton, dim3(b256), dim3(256), 0, s, sg->d, n, make_float3(blo[0], blo[1], blo[2]), make_float3(binv[0], binv[1], binv[2]), keys, vals);
-    size_t sort_bytes = 0;
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_s, vals, vals_s, (int)n, 0, 30, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: sort setup failed"));
-    size_t scan_bytes = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, s) != hipSuccess) return done(fail(LPT_ERR_HIP, "GPU BVH build: scan setup failed"));
     void *cub_tmp = scratch(std::max(sort_bytes, scan_bytes));
     if (!cub_tmp) return done(fail(LPT_ERR_HIP, "GPU BVH build: out of device memory"));
     size_t cub_bytes = std::max(sort_bytes, scan_bytes);
@@ -210,9 +233,13 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     LB_TRY(hipMalloc(&sg->node_hi, sizeof(float4) * (size_t)n_nodes));
     // Woop maps: prim order (host, double precision) -> leaf order
     LB_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)n));
-    SCR(float4, woop_prim, 3u * (size_t)n)
-    LB_TRY(hipMemcpyAsync(woop_prim, acc.woop.data(), sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(b256), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)tri_slot, n);
+    const float4 *woop_src = dev_woop;
+    if (host_woop) {
+        SCR(float4, woop_prim, 3u * (size_t)n)
+        LB_TRY(hipMemcpyAsync(woop_prim, host_woop, sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
+        woop_src = woop_prim;
+    }
+    hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(b256), dim3(256), 0, s, woop_src, (float4 *)sg->woop, (const uint32_t *)tri_slot, n);
     sg->d.nodes = (const DNode8 *)sg->nodes;
     sg->d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     sg->d.woop = (const float4 *)sg->woop;
@@ -228,6 +255,22 @@ static int build_lbvh(lpt_scene_gpu *sg, const Accel &acc, hipStream_t s) {
     return st;
 #undef LB_TRY
 #undef SCR
+}
+
+// kernel arguments for re-baking instance i on the device (k_bake_instance)
+static int make_bake_args(const lpt_scene &scene, size_t i, uint32_t first, uint32_t n, BakeArgs &a) {
+    const lpt_instance &now = scene.instances[i];
+    const lpt_blas_entry &e = scene.entries[now.blas_index];
+    if (e.index_count / 3u != n) return fail(LPT_ERR_INVALID_ARG, "triangle count of instance %zu changed since the upload", i);
+    memcpy(a.m, now.model_to_world, sizeof a.m);
+    const float *m = a.m;
+    const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
+    a.c[0] = a11 * a22 - a12 * a21; a.c[1] = a12 * a20 - a10 * a22; a.c[2] = a10 * a21 - a11 * a20;   // bvh.cpp bake_one
+    a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
+    a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
+    a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
+    memcpy(a.mat, &scene.materials[now.material_index < scene.materials.size() ? now.material_index : 0u], 32);
+    return LPT_OK;
 }
 
 extern "C" {
@@ -288,7 +331,7 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     hipSetDevice(sg->dev->ordinal);
     hipStreamSynchronize(sg->dev->stream);
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
-                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag};
+                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
     return LPT_OK;
@@ -401,7 +444,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     sg->stats.max_depth = acc.max_depth;
     sg->stats.build_ms = acc.build_ms;
     if (gpu_build) {
-        st = build_lbvh(sg, acc, s);
+        st = build_lbvh(sg, (uint32_t)acc.tri_material.size(), acc.woop.data(), nullptr, s);
         if (st != LPT_OK) { lpt_scene_gpu_destroy(sg); return st; }
         d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
     }
@@ -436,17 +479,9 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         const uint32_t first = sg->inst_first[i], n = sg->inst_count[i];
         if (n) {
             // re-bake on the device: the object-space mesh is resident, only the transform travels
-            const lpt_blas_entry &e = scene->entries[now.blas_index];
-            if (e.index_count / 3u != n) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: triangle count of instance %zu changed", i);
             BakeArgs a;
-            memcpy(a.m, now.model_to_world, sizeof a.m);
-            const float *m = a.m;
-            const float a00 = m[0], a10 = m[1], a20 = m[2], a01 = m[4], a11 = m[5], a21 = m[6], a02 = m[8], a12 = m[9], a22 = m[10];
-            a.c[0] = a11 * a22 - a12 * a21; a.c[1] = a12 * a20 - a10 * a22; a.c[2] = a10 * a21 - a11 * a20;   // bvh.cpp bake_one
-            a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
-            a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
-            a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
-            memcpy(a.mat, &scene->materials[now.material_index < scene->materials.size() ? now.material_index : 0u], 32);
+            int bst = make_bake_args(*scene, i, first, n, a);
+            if (bst != LPT_OK) return bst;
             hipLaunchKernelGGL(k_bake_instance, dim3(div_up(n, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
                                (float4 *)sg->tri_verts, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
         }
@@ -471,6 +506,48 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (out_rebaked) *out_rebaked = changed;
+    return LPT_OK;
+}
+
+// Full rebuild on the GPU for scenes whose instances moved far (a refit keeps the old topology and degrades): every
+// instance is re-baked on the device and the tree is rebuilt there (build_kernels.h).  Same preconditions as
+// lpt_scene_gpu_update_instances; scenes of fewer than 16 triangles are refitted instead.
+int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
+    if (!sg || !scene) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_rebuild: null");
+    if (scene->instances.size() != sg->instances.size() || scene->entries.size() != sg->n_entries ||
+        scene->vertices.size() != sg->n_vertices || scene->indices.size() != sg->n_indices)
+        return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_rebuild: the scene's meshes / instance list changed since the upload; upload again");
+    const uint32_t n = sg->stats.triangles;
+    if (n < 16u) return lpt_scene_gpu_update_instances(sg, scene, nullptr);
+    HIP_TRY(hipSetDevice(sg->dev->ordinal));
+    hipStream_t s = sg->dev->stream;
+    void *woop_prim = nullptr;
+    HIP_TRY(hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)n));
+    for (size_t i = 0; i < scene->instances.size(); ++i) {
+        if (scene->instances[i].blas_index != sg->instances[i].blas_index) { hipFree(woop_prim); return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_rebuild: instance %zu refers to another mesh; upload again", i); }
+        const uint32_t first = sg->inst_first[i], cnt = sg->inst_count[i];
+        if (!cnt) continue;
+        BakeArgs a;
+        int bst = make_bake_args(*scene, i, first, cnt, a);
+        if (bst != LPT_OK) { hipFree(woop_prim); return bst; }
+        hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
+                           (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
+    }
+    uint32_t bad = 0;
+    hipError_t e = hipMemcpyAsync(&bad, sg->bad_flag, sizeof bad, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess || bad) {
+        hipMemsetAsync(sg->bad_flag, 0, sizeof bad, s);
+        hipFree(woop_prim);
+        return e != hipSuccess ? fail(LPT_ERR_HIP, "lpt_scene_gpu_rebuild: %s", hipGetErrorString(e)) : fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in a re-baked instance");
+    }
+    void **old[] = {&sg->nodes, &sg->woop, &sg->leaf_prim, &sg->tri_slot, &sg->node_lo, &sg->node_hi};
+    for (void **p : old) { if (*p) hipFree(*p); *p = nullptr; }
+    int st = build_lbvh(sg, n, nullptr, (const float4 *)woop_prim, s);
+    hipFree(woop_prim);
+    if (st != LPT_OK) return st;
+    sg->d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
+    sg->instances = scene->instances;
     return LPT_OK;
 }
 

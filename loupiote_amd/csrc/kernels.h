@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 
     tri_verts[kTriRec * (size_t)(a.first_tri + t) + 7u] = a.mat[1];
     float4 w[3];
     woop_device(P[0], P[1], P[2], w);
-    const uint32_t slot = tri_slot[a.first_tri + t];
+    const uint32_t slot = tri_slot ? tri_slot[a.first_tri + t] : a.first_tri + t;  // no slot table: prim order (full rebuild)
     woop[3u * (size_t)slot] = w[0]; woop[3u * (size_t)slot + 1] = w[1]; woop[3u * (size_t)slot + 2] = w[2];
 }
 
