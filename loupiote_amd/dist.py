@@ -97,7 +97,7 @@ def exchange_denoiser_inputs(renderer, device, dst=0, stream=None):
             torch.as_tensor(DevView(motion, 2 * n, "<f4"), device=device)]
     ctx = torch.cuda.stream(stream) if stream is not None else _null()
     with ctx:
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():
             for b in bufs:
                 dist.reduce(b, dst=dst, op=dist.ReduceOp.SUM)
     if not dist.is_initialized() or dist.get_rank() == dst:

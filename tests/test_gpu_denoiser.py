@@ -143,3 +143,14 @@ def test_sharded_denoising_equals_single_gpu(device, cornell_glb):
     for r in (single, a, b):
         r.close()
     pr.close(); sg.close()
+
+
+def test_exchange_plumbing_on_device_pointers():
+    """one-rank RCCL group: exchange_denoiser_inputs / reduce_radiance / OwnedTileGather on real device pointers
+    (tests/tools/dist_den_check.py, in a subprocess so that the process group does not leak into this session)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "dist_den_check.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "dist-den-check ok" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
