@@ -18,6 +18,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build the library once (hipcc cross-compiles
+    # gfx950 without a GPU; `make` is a no-op when it is up to date).  The oracle builds itself on import.
+    so = os.path.join(ROOT, "loupiote_amd", "libloupiote_hip.so")
+    if not os.path.exists(so):
+        from loupiote_amd import build
+        build.build()
 
 
 @pytest.fixture(scope="session")
