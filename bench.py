@@ -32,6 +32,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import loupiote_amd as lp  # noqa: E402
+
+if not os.path.exists(lp.LIB_PATH):  # the built library normally travels with the tree; a fresh checkout builds it (hipcc, ~1 min)
+    from loupiote_amd import build as _build
+    _build.build()
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 4, 8
