@@ -34,8 +34,14 @@ import torch.distributed as dist  # noqa: E402
 import loupiote_amd as lp  # noqa: E402
 
 if not os.path.exists(lp.LIB_PATH):  # the built library normally travels with the tree; a fresh checkout builds it (hipcc, ~1 min)
-    from loupiote_amd import build as _build
-    _build.build()
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        from loupiote_amd import build as _build
+        _build.build()
+    else:  # one builder per node; the other ranks wait for the file
+        _t0 = time.time()
+        while not os.path.exists(lp.LIB_PATH) and time.time() - _t0 < 900:
+            time.sleep(1.0)
+        time.sleep(2.0)
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 4, 8
