@@ -238,6 +238,10 @@ int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32
  * LPT_ERR_FILE_NOT_FOUND when the data is not a decodable "-Y H +X W" 32-bit_rle_rgbe image. */
 int lpt_decode_hdr(const uint8_t *data, size_t size, uint8_t *rgbe8, size_t capacity, uint32_t *width, uint32_t *height);
 
+/* new (the linear-radiance counterpart of lpt_write_png): RGBA float rows (e.g. lpt_renderer_read_radiance)
+ * as a Radiance RGBE .hdr file (alpha dropped, negative / NaN -> 0).  row_floats = floats between row starts (>= 4*width). */
+int lpt_write_hdr(const char *path, const float *rgba, uint32_t width, uint32_t height, size_t row_floats);
+
 /* ---- SceneGPU / ProbeGPU --------------------------------------------------
  * replaces: SceneGPU::new_from_scene(&Scene,&Device,&Queue)
  * (crates/lib/src/scene.rs:151-188).  Bakes every instance into world space,

@@ -454,6 +454,13 @@ def save_screenshot(renderer, path):
     _check(A.lib().lpt_write_png(str(path).encode(), A.ptr(px), px.shape[1], px.shape[0], px.shape[1] * 4))
 
 
+def save_radiance(renderer_or_array, path):
+    """linear radiance (Renderer.read_radiance() or an (h, w, 4) float32 array) -> Radiance RGBE .hdr file"""
+    a = renderer_or_array.read_radiance() if hasattr(renderer_or_array, "read_radiance") else renderer_or_array
+    a = np.ascontiguousarray(a, np.float32)
+    _check(A.lib().lpt_write_hdr(str(path).encode(), A.ptr(a), a.shape[1], a.shape[0], a.shape[1] * 4))
+
+
 class CameraController:
     """Convention-only mirror of crates/standalone/src/camera.rs:46-116: `update()` returns the
     camera-to-world Mat4 = T(origin) * [right up direction W] (column-major, 16 floats)."""

@@ -4,6 +4,9 @@
 // are stored — 4 bytes per pixel, shared exponent — so this decoder only undoes the run-length coding.
 // Supported: "#?RADIANCE" / "#?RGBE" headers, FORMAT=32-bit_rle_rgbe, the standard "-Y H +X W" orientation,
 // flat scanlines, old-style RLE runs and the new per-channel RLE (scanline widths 8..32767).
+#include <algorithm>
+#include <cmath>
+
 #include "common.h"
 
 namespace lpt {
@@ -101,4 +104,35 @@ extern "C" int lpt_decode_hdr(const uint8_t *data, size_t size, uint8_t *rgbe8, 
         memcpy(rgbe8, px.data(), px.size());
     }
     return LPT_OK;
+}
+
+// Radiance writer for linear radiance (the "EXR / HDR" half of SURVEY §8f-4; the reference only saves the tonemapped
+// PNG, app.rs:172-187): RGB floats -> shared-exponent RGBE (mantissas truncated as in Ward's float2rgbe), flat scanlines.
+extern "C" int lpt_write_hdr(const char *path, const float *rgba, uint32_t width, uint32_t height, size_t row_floats) {
+    if (!path || !rgba || !width || !height || row_floats < (size_t)width * 4) return lpt::fail(LPT_ERR_INVALID_ARG, "lpt_write_hdr: bad arguments");
+    FILE *f = fopen(path, "wb");
+    if (!f) return lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: cannot open %s for writing", path);
+    fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %u +X %u\n", height, width);
+    std::vector<uint8_t> row((size_t)width * 4);
+    bool ok = true;
+    for (uint32_t y = 0; y < height && ok; ++y) {
+        const float *src = rgba + (size_t)y * row_floats;
+        for (uint32_t x = 0; x < width; ++x) {
+            float r = src[4 * x], g = src[4 * x + 1], b = src[4 * x + 2];
+            if (!(r > 0.f)) r = 0.f;   // negative and NaN -> 0
+            if (!(g > 0.f)) g = 0.f;
+            if (!(b > 0.f)) b = 0.f;
+            const float m = std::max(r, std::max(g, b));
+            uint8_t *p = &row[4 * (size_t)x];
+            if (!(m >= 1e-32f) || !std::isfinite(m)) { p[0] = p[1] = p[2] = p[3] = 0; if (std::isfinite(m)) continue; }
+            if (!std::isfinite(m)) { p[0] = p[1] = p[2] = 255; p[3] = 255; continue; }
+            int e;
+            const float scale = std::frexp(m, &e) * 256.0f / m;   // m = f * 2^e, f in [0.5, 1)
+            p[0] = (uint8_t)(r * scale); p[1] = (uint8_t)(g * scale); p[2] = (uint8_t)(b * scale);
+            p[3] = (uint8_t)(e + 128);
+        }
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    fclose(f);
+    return ok ? LPT_OK : lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: short write to %s", path);
 }

@@ -299,3 +299,27 @@ def test_hdr_decoder_matches_oracle_and_source():
         with pytest.raises(lp.Error) as e:
             lp.load_env(bad)
         assert e.value.kind == "FileNotFound"
+
+
+def test_hdr_writer_round_trip(tmp_path):
+    """lpt_write_hdr -> file -> lpt_decode_hdr: the RGBE pixels are Ward's float2rgbe of the input and decode to within
+    one mantissa step (1/128 of the largest channel)"""
+    rng = np.random.default_rng(5)
+    img = np.zeros((9, 13, 4), np.float32)
+    img[..., :3] = np.exp(rng.uniform(-12, 8, (9, 13, 3))).astype(np.float32)
+    img[0, 0, :3] = 0; img[0, 1, :3] = (-1.0, np.nan, 2.0); img[0, 2, :3] = 1e-38; img[..., 3] = 1.0
+    path = tmp_path / "r.hdr"
+    lp.save_radiance(img, path)
+    px = lp.load_env_path(path)
+    assert px.shape == (9, 13, 4) and G.decode_hdr(open(path, "rb").read()).tobytes() == px.tobytes()
+    clean = np.where(img[..., :3] > 0, img[..., :3], 0).astype(np.float32)
+    m = clean.max(axis=2)
+    mant, e = np.frexp(m)
+    scale = np.where(m >= 1e-32, (mant.astype(np.float32) * np.float32(256.0) / np.where(m >= 1e-32, m, 1)).astype(np.float32), 0)
+    want = np.zeros_like(px)
+    want[..., :3] = (clean * scale[..., None]).astype(np.uint8)
+    want[..., 3] = np.where(m >= 1e-32, e + 128, 0)
+    want[m < 1e-32] = 0
+    assert px.tobytes() == want.tobytes()
+    dec = px[..., :3].astype(np.float64) * np.exp2(px[..., 3:4].astype(np.float64) - 136.0)
+    assert np.all(np.abs(dec - clean) <= m[..., None] / 128.0 + 1e-30)
