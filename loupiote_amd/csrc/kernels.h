@@ -81,6 +81,12 @@ struct FrameParams {
     uint32_t n_samples, fc_inc0;
 };
 
+// streaming accesses (ray queues, hit records): the `nt` hint keeps the ~400 MB that stream through a frame from
+// evicting the data that is reused (BVH, shading records, textures) from L2 / Infinity Cache
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p) { const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_nt(float4 *p, const float4 v) { const f4v w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(p)); }
+
 // pixel slot -> pixel.  Slots enumerate this rank's tiles (tile ids rank, rank+world, ...)
 // and the pixels inside each tile row-major, so a wave64 covers a 32x2 pixel block.
 __device__ __forceinline__ bool slot_to_pixel(const FrameParams &p, uint32_t slot, uint32_t &x, uint32_t &y) {
@@ -172,8 +178,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
         }
         const uint32_t idx = DENSE ? vslot : block_compact(valid, &ctr->qcount[0], lds);
         if (valid) {
-            q.o[idx] = make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(vslot));
-            q.d[idx] = make_float4(d.x, d.y, d.z, -1.0f);
+            st_nt(q.o + idx, make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(vslot)));
+            st_nt(q.d + idx, make_float4(d.x, d.y, d.z, -1.0f));
             q.T[idx] = make_float4(1.f, 1.f, 1.f, __uint_as_float(x | (y << 13) | (sample << 26)));  // pixel + sample ride along: no divisions in k_shade
         }
     }
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
                     }
                 } else {
                     intersect_lights(sc, rs.o, rs.d, rs.best);
-                    hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
+                    st_nt(hits + ray, make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim)));
                 }
                 finished = false;
             }
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
         bool want_next = false, want_shadow = false, is_surface = false;
         float4 no4, nd4, nT4, so4, sd4, sc4;
         if (i < count) {
-            const float4 o4 = qin.o[i], d4 = qin.d[i], T4 = qin.T[i], h4 = hits[i];
+            const float4 o4 = ld_nt(qin.o + i), d4 = ld_nt(qin.d + i), T4 = ld_nt(qin.T + i), h4 = ld_nt(hits + i);
             const uint32_t slot = __float_as_uint(o4.w);
             const uint32_t pxy = __float_as_uint(T4.w);  // x | y << 13 | sample << 26 (k_raygen)
             const f3 d = mk3(d4.x, d4.y, d4.z);
@@ -886,10 +892,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
             }
         }
         const uint32_t si = block_compact(want_shadow, &ctr->shcount[bounce], lds);
-        if (want_shadow) { sq.o[si] = so4; sq.d[si] = sd4; sq.c[si] = sc4; }
+        if (want_shadow) { st_nt(sq.o + si, so4); st_nt(sq.d + si, sd4); st_nt(sq.c + si, sc4); }
         if (!last_bounce) {
             const uint32_t ni = block_compact(want_next, &ctr->qcount[bounce + 1], lds);
-            if (want_next) { qout.o[ni] = no4; qout.d[ni] = nd4; qout.T[ni] = nT4; }
+            if (want_next) { st_nt(qout.o + ni, no4); st_nt(qout.d + ni, nd4); st_nt(qout.T + ni, nT4); }
         }
         n_surface += is_surface ? 1u : 0u;
     }
