@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LPT_ABI_VERSION 1u
+#define LPT_ABI_VERSION 2u
 
 /* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
 #define LPT_INVALID_INDEX 0xFFFFFFFFu
@@ -46,7 +46,7 @@ enum {
     LPT_ERR_READBACK = 2,       /* Error::TextureToBufferReadFail       */
     LPT_ERR_ACCEL_BUILD = 3,    /* Error::AccelBuild(String)            */
     LPT_ERR_HIP = 4,            /* a HIP runtime call failed / no GPU   */
-    LPT_ERR_RCCL = 5,           /* reserved for the collective path     */
+    LPT_ERR_RCCL = 5,           /* an RCCL call of the frame exchange failed */
     LPT_ERR_INVALID_ARG = 6
 };
 
@@ -158,6 +158,7 @@ typedef struct lpt_scene lpt_scene;
 typedef struct lpt_scene_gpu lpt_scene_gpu;
 typedef struct lpt_probe lpt_probe;
 typedef struct lpt_renderer lpt_renderer;
+typedef struct lpt_comm lpt_comm;
 
 /* ---- Device ---------------------------------------------------------------
  * replaces: Device::new(wgpu::Device) (crates/lib/src/device.rs:80).  One
@@ -356,7 +357,7 @@ int lpt_renderer_set_seed(lpt_renderer *r, uint32_t user_seed);
 int lpt_renderer_set_vfov(lpt_renderer *r, float radians);
 /* Pixel-tile sharding for one-process-per-GPU rendering: this process traces
  * the tiles whose index (row-major over ceil(w/tile_w) × ceil(h/tile_h)) is
- * ≡ rank (mod world_size).  Default (0,1,32,8) = everything. */
+ * ≡ rank (mod world_size).  Default (0,1,32,8) = everything.  The tile area must be a multiple of 64 (one wave). */
 int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world_size, uint32_t tile_w,
                            uint32_t tile_h);
 /* new (multi-GPU denoising; reference: asvgf passes run on the one GPU, renderer.rs:513-522).  With set_shard(world > 1)
@@ -367,11 +368,63 @@ int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world_size, 
  * iterations and the composite over the whole frame on that rank (no-op for world == 1: raytrace() already did). */
 int lpt_renderer_denoiser_inputs(lpt_renderer *r, void **noisy, void **gbuffer, void **motion, size_t *n_pixels);
 int lpt_renderer_denoise_filter(lpt_renderer *r);
-/* Device address + byte size of the fp32 RGBA accumulation buffer
- * (rgb = radiance SUM, a = sample count; zero where not owned).  The collective
- * layer sums it across ranks (RCCL reduce) before read_radiance on rank 0. */
+/* Device address + byte size of the fp32 RGBA accumulation buffer (rgb = radiance SUM, a = sample count; zero where
+ * not owned) for hosts that run their own collective.  Such a host must combine into a buffer of its own: this one is
+ * rewritten only on owned pixels, so an in-place reduce would count rank 0's foreign pixels again on the next frame
+ * (lpt_renderer_exchange avoids that with a separate presented frame). */
 int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **device_ptr, size_t *bytes);
+/* ---- multi-GPU frame exchange (new functionality: the reference is single-GPU; its Device::new is
+ * crates/lib/src/device.rs:79 and the only caller of Renderer::raytrace / read_pixels is the one-threaded event loop,
+ * crates/standalone/src/app.rs:297-318).  North star: frames shard by pixel tile across the GPUs of a node and the
+ * accumulated radiance is combined on rank 0 with RCCL over xGMI.  Everything below is plain RCCL inside the library:
+ * a Rust (or any other) host needs no torch.
+ *
+ *   one process per GPU                          | one process, several GPUs
+ *   rank 0: lpt_comm_unique_id(id); ship the     | lpt_comm_unique_id(id); lpt_comm_group_begin();
+ *   128 bytes to the other ranks out of band     | for i in 0..n: lpt_comm_create(dev[i], id, i, n, &comm[i]);
+ *   every rank: lpt_comm_create(dev, id, rank,   | lpt_comm_group_end();   (and the per-frame exchanges of the n
+ *   world, &comm)                                | renderers inside a begin/end pair as well)
+ *
+ * Then per renderer: lpt_renderer_set_comm(r, comm) (= set_shard(rank, world, 32, 8) + the binding), and per frame
+ * raytrace(...) [x spp]; lpt_renderer_exchange(r, mode); on rank 0 read_radiance / read_pixels / blit return the whole
+ * frame.  The exchange is enqueued on the renderer's stream behind the frame's kernels (no host synchronisation), so
+ * with several renderers the exchange of frame k overlaps the kernels of frame k+1. */
+#define LPT_COMM_ID_BYTES 128
+/* replaces: nothing (ncclGetUniqueId).  Call once, on one rank. */
+int lpt_comm_unique_id(void *out_id /* LPT_COMM_ID_BYTES */);
+/* ncclCommInitRank on `dev`.  Collective over the `world_size` callers; LPT_ERR_RCCL on failure. */
+int lpt_comm_create(lpt_device *dev, const void *id /* LPT_COMM_ID_BYTES */, int rank, int world_size, lpt_comm **out);
+int lpt_comm_destroy(lpt_comm *comm);
+int lpt_comm_info(const lpt_comm *comm, int *rank, int *world_size);
+/* ncclGroupStart / ncclGroupEnd: needed only when ONE thread drives several communicators (right column above). */
+int lpt_comm_group_begin(void);
+int lpt_comm_group_end(void);
+
+enum {
+    /* every rank sends only the pixels it owns (W*H/N * 16 B; 4 MB per rank at 1080p, N = 8) straight to rank 0 —
+     * grouped ncclSend / ncclRecv, seven xGMI links in parallel — which scatters them into the frame.  Default. */
+    LPT_EXCHANGE_GATHER_TILES = 0,
+    /* ncclReduce(sum, root 0) of the full-frame accumulation buffers (zero outside a rank's tiles): the literal form the
+     * north star names; 33 MB around a ring at 1080p.  Bit-identical result (x + 0 = x). */
+    LPT_EXCHANGE_REDUCE = 1
+};
+/* Binds a communicator (NULL unbinds: single-GPU again).  Implies lpt_renderer_set_shard(rank, world, 32, 8) with the
+ * communicator's rank / size and therefore resets the accumulation. */
+int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm_or_null);
+/* Combines the ranks' accumulation buffers into rank 0's PRESENTED frame (a separate full-frame buffer: every rank's own
+ * accumulation buffer stays owned-pixels-only, so progressive frames can be exchanged again and again).  Collective over
+ * the communicator; asynchronous; a no-op without a communicator.  In the denoising BlitModes it exchanges the filter
+ * inputs instead (lpt_renderer_denoiser_inputs) and runs lpt_renderer_denoise_filter on rank 0. */
+int lpt_renderer_exchange(lpt_renderer *r, int mode);
+/* The same exchange among renderers of ONE process without RCCL (peer copies): `root` presents the frame assembled from
+ * its own tiles and those of `peers` (n_peers renderers sharded with the same world size and tile shape, on the same or
+ * on other devices of the process).  Used by single-process hosts and by the tests that emulate N ranks on one GPU. */
+int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers);
+
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
+/* per-bounce queue sizes of the LAST traced frame: closest[b] = closest-hit rays of bounce b, shadow[b] = shadow rays
+ * emitted by bounce b; up to `cap` entries each (either pointer may be NULL).  Blocking. */
+int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *shadow, uint32_t cap);
 int lpt_renderer_reset_ray_counts(lpt_renderer *r);
 /* count BVH nodes visited / triangles tested per ray (slower kernel variant) */
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag);

@@ -18,6 +18,9 @@ LPT_ERR_ACCEL_BUILD = 3
 LPT_ERR_HIP = 4
 LPT_ERR_RCCL = 5
 LPT_ERR_INVALID_ARG = 6
+COMM_ID_BYTES = 128
+EXCHANGE_GATHER_TILES = 0
+EXCHANGE_REDUCE = 1
 INVALID_INDEX = 0xFFFFFFFF
 LIGHT_BIT = 0x80000000
 
@@ -126,6 +129,16 @@ SIGNATURES = {
     "lpt_renderer_radiance_device_ptr": (_i, [_vp, _pvp, C.POINTER(_sz)]),
     "lpt_renderer_denoiser_inputs": (_i, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "lpt_renderer_denoise_filter": (_i, [_vp]),
+    "lpt_comm_unique_id": (_i, [_vp]),
+    "lpt_comm_create": (_i, [_vp, _vp, _i, _i, _pvp]),
+    "lpt_comm_destroy": (_i, [_vp]),
+    "lpt_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "lpt_comm_group_begin": (_i, []),
+    "lpt_comm_group_end": (_i, []),
+    "lpt_renderer_set_comm": (_i, [_vp, _vp]),
+    "lpt_renderer_exchange": (_i, [_vp, _i]),
+    "lpt_renderer_exchange_local": (_i, [_vp, _pvp, _i]),
+    "lpt_renderer_get_queue_counts": (_i, [_vp, _vp, _vp, _u32]),
     "lpt_renderer_get_ray_counts": (_i, [_vp, C.POINTER(RayCounts)]),
     "lpt_renderer_reset_ray_counts": (_i, [_vp]),
     "lpt_renderer_enable_stats": (_i, [_vp, _i]),

@@ -71,6 +71,35 @@ class Device:
             self._h = None
 
 
+class Comm:
+    """One rank of the frame exchange (new functionality, include/lpt.h "multi-GPU frame exchange"): a plain RCCL
+    communicator owned by the library.  `Comm.unique_id()` on one rank, ship the 128 bytes, `Comm(device, id, rank, world)`
+    on every rank (collective)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(A.COMM_ID_BYTES)
+        _check(A.lib().lpt_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, device, unique_id, rank, world_size):
+        if len(unique_id) != A.COMM_ID_BYTES:
+            raise Error(A.LPT_ERR_INVALID_ARG, "unique id must be %d bytes" % A.COMM_ID_BYTES)
+        h = C.c_void_p()
+        _check(A.lib().lpt_comm_create(device.inner(), C.c_char_p(bytes(unique_id)), int(rank), int(world_size), C.byref(h)))
+        self._h = h
+
+    def info(self):
+        r, w = C.c_int(), C.c_int()
+        _check(A.lib().lpt_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def close(self):
+        if self._h:
+            A.lib().lpt_comm_destroy(self._h)
+            self._h = None
+
+
 class Scene:
     """scene.rs:30-54 — `Scene::default()` holds one dummy element in every array."""
 
@@ -379,6 +408,25 @@ class Renderer:
 
     def set_shard(self, rank, world_size, tile_w=32, tile_h=8):
         _check(A.lib().lpt_renderer_set_shard(self._h, rank, world_size, tile_w, tile_h))
+
+    def set_comm(self, comm):
+        """bind a `Comm` (None unbinds); implies set_shard(rank, world, 32, 8)"""
+        _check(A.lib().lpt_renderer_set_comm(self._h, comm._h if comm is not None else None))
+
+    def exchange(self, mode=A.EXCHANGE_GATHER_TILES):
+        """combine the ranks' frames into rank 0's presented frame (RCCL, asynchronous on the renderer's stream)"""
+        _check(A.lib().lpt_renderer_exchange(self._h, int(mode)))
+
+    def exchange_local(self, peers):
+        """the same exchange among sharded renderers of this process (self = rank 0) without RCCL"""
+        arr = (C.c_void_p * max(len(peers), 1))(*[p._h for p in peers])
+        _check(A.lib().lpt_renderer_exchange_local(self._h, arr, len(peers)))
+
+    def queue_counts(self, n=64):
+        """per-bounce (closest-hit, shadow) queue sizes of the last traced frame"""
+        c, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        _check(A.lib().lpt_renderer_get_queue_counts(self._h, A.ptr(c), A.ptr(s), n))
+        return c, s
 
     def radiance_device_ptr(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -210,12 +210,15 @@ void bake(const lpt_scene &s, Accel &out) {
 // The binary tree is built down to single triangles so that the leaves are formed here.
 struct Kid { int32_t node; bool leaf; };
 struct Collapse {
-    static constexpr float kNodeCost = 1.0f, kPrimCost = 0.3f;
+    // relative cost of visiting an 8-wide node and of testing one triangle (LPT_BVH_PRIM_COST: experiments)
+    static constexpr float kNodeCost = 1.0f;
+    float kPrimCost = 0.3f;
     const std::vector<BuildNode> &n;
     std::vector<float> C;        // [7 * node + i - 1]
     std::vector<uint8_t> how;    // i == 1: 1 = 8-wide node, 0 = leaf;  i >= 2: 0 = same as C(n,i-1), else k of D(n,i)
     std::vector<uint8_t> k8;     // k of D(n,8), used when n becomes an 8-wide node
     explicit Collapse(const std::vector<BuildNode> &nodes) : n(nodes), C(7 * nodes.size()), how(7 * nodes.size(), 0), k8(nodes.size(), 0) {
+        if (const char *ev = getenv("LPT_BVH_PRIM_COST")) { const float v = (float)atof(ev); if (v > 0.f) kPrimCost = v; }
         for (size_t id = nodes.size(); id-- > 0;) {
             const BuildNode &b = n[id];
             const float A = b.box.half_area();
@@ -448,7 +451,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
                 // leaf child: unary triangle count in the top 3 bits, offset from tri_base in the low 5
                 node.meta[sl] = (uint8_t)((((1u << c.pcount) - 1u) << 5) | tri_off);
                 stat_leaf_tris[c.pcount]++;
-                sah += (double)c.box.half_area() * c.pcount * Collapse::kPrimCost;
+                sah += (double)c.box.half_area() * c.pcount * 0.3;
                 for (uint32_t t = 0; t < c.pcount; ++t) {
                     const uint32_t prim = b.refs[c.pfirst + t].prim;
                     const lpt_vertex *v = &out.tri_verts[3 * (size_t)prim];

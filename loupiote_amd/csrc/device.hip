@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "build_kernels.h"
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
 
 using namespace lpt;
 using namespace lptd;
@@ -31,6 +32,19 @@ struct lpt_device {
     int compute_units = 0;
     char name[128] = {0};
 };
+
+// one RCCL communicator rank (frame exchange); created by lpt_comm_create
+struct lpt_comm {
+    lpt_device *dev = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+#define RCCL_TRY(expr)                                                                                \
+    do {                                                                                              \
+        ncclResult_t r__ = (expr);                                                                    \
+        if (r__ != ncclSuccess) return fail(LPT_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r__)); \
+    } while (0)
 
 struct lpt_scene_gpu {
     lpt_device *dev = nullptr;
@@ -88,6 +102,14 @@ struct lpt_renderer {
     Queue q[2]{};
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr, *accum = nullptr, *scratch = nullptr;
+    // frame exchange (lpt_renderer_exchange): `frame` = the presented whole frame on rank 0 (accum stays owned-only),
+    // `xstage` = packed owned tiles (this rank's; on rank 0 those of every rank, concatenated)
+    lpt_comm *comm = nullptr;
+    float4 *frame = nullptr, *xstage = nullptr;
+    size_t xstage_elems = 0;
+    bool presented = false;   // read_radiance / read_pixels / blit resolve from `frame` (set by an exchange, cleared by raytrace)
+    hipEvent_t xevent = nullptr;
+    bool xevent_recorded = false;
     FrameCounters *ctr = nullptr;
     Totals *totals = nullptr;
     void *default_probe = nullptr;
@@ -118,6 +140,8 @@ struct lpt_renderer {
 };
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+// what read_radiance / read_pixels / blit show: the exchanged whole frame after lpt_renderer_exchange, else the local target
+static inline const float4 *presented_target(const lpt_renderer *r) { return (r->presented && r->frame) ? r->frame : r->accum; }
 static inline size_t stack_bytes(const DScene &sc) { return (size_t)sc.stack_entries * kTraceBlock * sizeof(uint2); }
 
 template <typename T>
@@ -469,6 +493,9 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         return fail(LPT_ERR_INVALID_ARG, "lpt_scene_gpu_update_instances: the scene's meshes / instance list changed since the upload; upload again");
     HIP_TRY(hipSetDevice(sg->dev->ordinal));
     hipStream_t s = sg->dev->stream;
+    // renderers trace on their own streams and raytrace() is asynchronous: frames still in flight read the triangles and
+    // nodes this call rewrites in place, so wait for every stream of the device first
+    HIP_TRY(hipDeviceSynchronize());
     uint32_t changed = 0;
     for (size_t i = 0; i < scene->instances.size(); ++i) {
         const lpt_instance &now = scene->instances[i];
@@ -521,6 +548,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
     if (n < 16u) return lpt_scene_gpu_update_instances(sg, scene, nullptr);
     HIP_TRY(hipSetDevice(sg->dev->ordinal));
     hipStream_t s = sg->dev->stream;
+    HIP_TRY(hipDeviceSynchronize());  // frames in flight on the renderers' streams still read what is rebuilt here
     void *woop_prim = nullptr;
     HIP_TRY(hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)n));
     for (size_t i = 0; i < scene->instances.size(); ++i) {
@@ -541,11 +569,33 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
         hipFree(woop_prim);
         return e != hipSuccess ? fail(LPT_ERR_HIP, "lpt_scene_gpu_rebuild: %s", hipGetErrorString(e)) : fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in a re-baked instance");
     }
-    void **old[] = {&sg->nodes, &sg->woop, &sg->leaf_prim, &sg->tri_slot, &sg->node_lo, &sg->node_hi};
-    for (void **p : old) { if (*p) hipFree(*p); *p = nullptr; }
+    // build into NEW buffers and swap them in only on success: a failed build (out of memory, node budget) leaves the
+    // scene exactly as it was, so bound renderers and later updates never see freed memory
+    void **slots[] = {&sg->nodes, &sg->woop, &sg->leaf_prim, &sg->tri_slot, &sg->node_lo, &sg->node_hi};
+    void *old[6];
+    for (int k = 0; k < 6; ++k) { old[k] = *slots[k]; *slots[k] = nullptr; }
+    const DScene old_d = sg->d;
+    const lpt_accel_stats old_stats = sg->stats;
+    const std::vector<uint32_t> old_levels = sg->level_start;
     int st = build_lbvh(sg, n, nullptr, (const float4 *)woop_prim, s);
+    if (st != LPT_OK) {
+        for (int k = 0; k < 6; ++k) { if (*slots[k]) hipFree(*slots[k]); *slots[k] = old[k]; }
+        sg->d = old_d; sg->stats = old_stats; sg->level_start = old_levels;
+        // the shading records were re-baked in place: put the old tree back in step with them (new Woop maps into the
+        // old leaf order, boxes refitted; topology kept)
+        hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(n, 256u)), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, n);
+        if (sg->stats.triangles)
+            for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
+                const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
+                if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
+            }
+        hipStreamSynchronize(s);
+        hipFree(woop_prim);
+        sg->instances = scene->instances;  // what is baked now
+        return st;
+    }
     hipFree(woop_prim);
-    if (st != LPT_OK) return st;
+    for (int k = 0; k < 6; ++k) if (old[k]) hipFree(old[k]);
     sg->d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
     sg->instances = scene->instances;
     return LPT_OK;
@@ -676,6 +726,12 @@ static void free_frame_buffers(lpt_renderer *r) {
     for (void *p : ptrs) if (p) hipFree(p);
     r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
     r->hits = r->Lsum = r->accum = r->scratch = nullptr;
+    if (r->frame) hipFree(r->frame);
+    if (r->xstage) hipFree(r->xstage);
+    r->frame = r->xstage = nullptr;
+    r->xstage_elems = 0;
+    r->xevent_recorded = false;
+    r->presented = false;
     r->n_slots = 0;
 }
 
@@ -766,6 +822,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->n_slots_host) hipHostFree(r->n_slots_host);
+    if (r->xevent) hipEventDestroy(r->xevent);
     if (r->stream) hipStreamDestroy(r->stream);
     if (r->noise) hipFree(r->noise);
     if (r->ev_start) {
@@ -978,6 +1035,7 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     if (!r->w || !r->h) return LPT_OK;
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     hipStream_t s = r->stream;
+    r->presented = false;                        // a new sample: the exchanged frame (if any) is stale
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
 
     FrameParams p;
@@ -1143,7 +1201,7 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);
     const uint32_t n = r->w * r->h;
-    if (e == hipSuccess) { hipLaunchKernelGGL(k_resolve, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->accum, r->scratch, n); e = hipGetLastError(); }
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_resolve, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, presented_target(r), r->scratch, n); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
@@ -1160,7 +1218,7 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
             hipLaunchKernelGGL(k_debug_view, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->den_gbuf[r->den_cur], r->den_motion,
                                (uchar4 *)r->scratch, (int)r->w, (int)r->h, r->mode);
         else
-            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->accum, (uchar4 *)r->scratch, n);
+            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, presented_target(r), (uchar4 *)r->scratch, n);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->stream);
@@ -1251,6 +1309,200 @@ int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count)
     const int n = std::min(*inout_count, (int)ST_COUNT);
     if (out) for (int i = 0; i < n; ++i) out[i] = acc[i];
     *inout_count = ST_COUNT;
+    return LPT_OK;
+}
+
+int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *shadow, uint32_t cap) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_queue_counts: null");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    const uint32_t n = std::min<uint32_t>(cap, (uint32_t)kMaxBounces);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (closest && n) HIP_TRY(hipMemcpy(closest, r->ctr->qcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    if (shadow && n) HIP_TRY(hipMemcpy(shadow, r->ctr->shcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    return LPT_OK;
+}
+
+// ============================================================================ multi-GPU frame exchange
+int lpt_comm_unique_id(void *out_id) {
+    if (!out_id) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_unique_id: null");
+    static_assert(sizeof(ncclUniqueId) == LPT_COMM_ID_BYTES, "LPT_COMM_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId id;
+    RCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(out_id, &id, sizeof id);
+    return LPT_OK;
+}
+
+int lpt_comm_create(lpt_device *dev, const void *id_bytes, int rank, int world, lpt_comm **out) {
+    if (!dev || !id_bytes || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_create: null");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_create: rank %d of %d", rank, world);
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    lpt_comm *c = new (std::nothrow) lpt_comm();
+    if (!c) return fail(LPT_ERR_INVALID_ARG, "out of host memory");
+    c->dev = dev; c->rank = rank; c->world = world;
+    ncclResult_t st = ncclCommInitRank(&c->comm, world, id, rank);
+    if (st != ncclSuccess) { delete c; return fail(LPT_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(st)); }
+    *out = c;
+    return LPT_OK;
+}
+
+int lpt_comm_destroy(lpt_comm *c) {
+    if (!c) return LPT_OK;
+    hipSetDevice(c->dev->ordinal);
+    if (c->comm) ncclCommDestroy(c->comm);
+    delete c;
+    return LPT_OK;
+}
+
+int lpt_comm_info(const lpt_comm *c, int *rank, int *world) {
+    if (!c) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_info: null");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return LPT_OK;
+}
+
+int lpt_comm_group_begin(void) { RCCL_TRY(ncclGroupStart()); return LPT_OK; }
+int lpt_comm_group_end(void) { RCCL_TRY(ncclGroupEnd()); return LPT_OK; }
+
+int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: null");
+    if (comm && comm->dev != r->dev) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: the communicator belongs to another device");
+    r->comm = comm;
+    return comm ? lpt_renderer_set_shard(r, (uint32_t)comm->rank, (uint32_t)comm->world, 32u, 8u) : lpt_renderer_set_shard(r, 0u, 1u, 32u, 8u);
+}
+
+}  // extern "C"
+
+// the sharding half of FrameParams (what k_pack_owned / k_unpack_frame read)
+static FrameParams shard_params(const lpt_renderer *r) {
+    FrameParams p{};
+    p.width = r->w; p.height = r->h;
+    p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
+    shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
+    return p;
+}
+static uint32_t slots_of_rank(const FrameParams &p, uint32_t q) {
+    return shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q + 1u) - shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q);
+}
+// `frame` (rank 0) and the staging area for packed tiles: this rank's slots, or every rank's on the root
+static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_stage) {
+    const size_t npx = (size_t)r->w * r->h;
+    if (!r->frame) HIP_TRY(hipMalloc(&r->frame, sizeof(float4) * std::max<size_t>(npx, 1)));
+    if (!r->xevent) HIP_TRY(hipEventCreateWithFlags(&r->xevent, hipEventDisableTiming));
+    if (!want_stage) return LPT_OK;
+    const FrameParams p = shard_params(r);
+    const size_t need = std::max<size_t>(root ? (size_t)p.n_tiles * p.tile_w * p.tile_h : (size_t)p.n_slots, 1);
+    if (r->xstage_elems < need) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->xstage) hipFree(r->xstage);
+        r->xstage = nullptr; r->xstage_elems = 0;
+        HIP_TRY(hipMalloc(&r->xstage, sizeof(float4) * need));
+        r->xstage_elems = need;
+    }
+    return LPT_OK;
+}
+static inline uint32_t stream_grid(const lpt_renderer *r, size_t n) {
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)r->dev->compute_units * 8u));
+}
+
+extern "C" {
+
+int lpt_renderer_exchange(lpt_renderer *r, int mode) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: null");
+    if (mode != LPT_EXCHANGE_GATHER_TILES && mode != LPT_EXCHANGE_REDUCE) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: unknown mode %d", mode);
+    if (!r->comm) return LPT_OK;   // single GPU: the local target is the frame
+    if (!r->w || !r->h || !r->accum) return LPT_OK;
+    lpt_comm *c = r->comm;
+    if ((uint32_t)c->rank != r->rank || (uint32_t)c->world != r->world)
+        return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: the renderer's shard (%u of %u) is not the communicator's (%d of %d); call lpt_renderer_set_comm again",
+                    r->rank, r->world, c->rank, c->world);
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    hipStream_t s = r->stream;
+    const bool root = c->rank == 0;
+    const size_t npx = (size_t)r->w * r->h;
+    if (r->mode != LPT_BLIT_PATHTRACE) {
+        // denoising BlitModes: the per-pixel filter inputs are what is exchanged (zero outside a rank's tiles, so the sums
+        // are gathers); rank 0 then filters the whole frame (SPEC §15.5)
+        if (!r->den_temp || !r->den_inputs_ready) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: no denoising frame has been traced");
+        RCCL_TRY(ncclReduce(r->den_noisy, r->den_noisy, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+        RCCL_TRY(ncclReduce(r->den_gbuf[r->den_cur], r->den_gbuf[r->den_cur], 4 * npx, ncclInt32, ncclSum, 0, c->comm, s));
+        RCCL_TRY(ncclReduce(r->den_motion, r->den_motion, 2 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+        if (root && r->world != 1u) { launch_filter(r, s); HIP_TRY(hipGetLastError()); }   // world == 1: raytrace() has filtered already
+        r->den_inputs_ready = false;
+        return LPT_OK;   // the composite has written the local target on rank 0
+    }
+    int st = ensure_exchange_buffers(r, root, mode == LPT_EXCHANGE_GATHER_TILES);
+    if (st != LPT_OK) return st;
+    const FrameParams p = shard_params(r);
+    if (mode == LPT_EXCHANGE_REDUCE) {
+        // every rank passes a valid receive buffer (only the root's is written)
+        RCCL_TRY(ncclReduce(r->accum, r->frame, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+    } else {
+        const uint32_t area = p.tile_w * p.tile_h;
+        if (p.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->accum, r->xstage);   // rank 0's offset is 0
+        if (root) {
+            RCCL_TRY(ncclGroupStart());
+            for (uint32_t q = 1; q < p.world; ++q) {
+                const uint32_t nq = slots_of_rank(p, q);
+                if (!nq) continue;
+                ncclResult_t e = ncclRecv(r->xstage + shard_slot_offset(p.n_tiles, p.world, area, q), 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
+                if (e != ncclSuccess) { ncclGroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, ncclGetErrorString(e)); }
+            }
+            RCCL_TRY(ncclGroupEnd());
+            hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->xstage, r->frame);
+        } else if (p.n_slots) {
+            RCCL_TRY(ncclSend(r->xstage, 4 * (size_t)p.n_slots, ncclFloat32, 0, c->comm, s));
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    r->presented = root;
+    return LPT_OK;
+}
+
+int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers) {
+    if (!root || n_peers < 0 || (n_peers && !peers)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: null");
+    if (root->rank != 0u || root->world != (uint32_t)n_peers + 1u)
+        return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: root must be rank 0 of %d (is %u of %u)", n_peers + 1, root->rank, root->world);
+    if (root->mode != LPT_BLIT_PATHTRACE) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: path-traced frames only");
+    if (!root->w || !root->h || !root->accum) return LPT_OK;
+    std::vector<char> seen(root->world, 0);
+    seen[0] = 1;
+    for (int i = 0; i < n_peers; ++i) {
+        const lpt_renderer *q = peers[i];
+        if (!q || q->w != root->w || q->h != root->h || q->world != root->world || q->tile_w != root->tile_w || q->tile_h != root->tile_h || q->rank >= root->world || seen[q->rank])
+            return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: peer %d does not complete the shard set of the root", i);
+        seen[q->rank] = 1;
+    }
+    HIP_TRY(hipSetDevice(root->dev->ordinal));
+    int st = ensure_exchange_buffers(root, true, true);
+    if (st != LPT_OK) return st;
+    const FrameParams p0 = shard_params(root);
+    const uint32_t area = p0.tile_w * p0.tile_h;
+    if (p0.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(root, p0.n_slots)), dim3(kBlock), 0, root->stream, p0, root->accum, root->xstage);
+    for (int i = 0; i < n_peers; ++i) {
+        lpt_renderer *q = peers[i];
+        HIP_TRY(hipSetDevice(q->dev->ordinal));
+        st = ensure_exchange_buffers(q, false, true);
+        if (st != LPT_OK) return st;
+        const FrameParams pq = shard_params(q);
+        // the root's staging area may still be read by the unpack of its previous exchange
+        if (root->xevent_recorded) HIP_TRY(hipStreamWaitEvent(q->stream, root->xevent, 0));
+        if (pq.n_slots) {
+            hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->accum, q->xstage);
+            // the stand-in of ncclSend / ncclRecv inside one process: a (peer) copy into the root's staging area
+            HIP_TRY(hipMemcpyPeerAsync(root->xstage + shard_slot_offset(pq.n_tiles, pq.world, area, pq.rank), root->dev->ordinal, q->xstage, q->dev->ordinal,
+                                       sizeof(float4) * (size_t)pq.n_slots, q->stream));
+        }
+        HIP_TRY(hipEventRecord(q->xevent, q->stream));
+        HIP_TRY(hipSetDevice(root->dev->ordinal));
+        HIP_TRY(hipStreamWaitEvent(root->stream, q->xevent, 0));
+    }
+    hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, root->xstage, root->frame);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(root->xevent, root->stream));
+    root->xevent_recorded = true;
+    root->presented = true;
     return LPT_OK;
 }
 

@@ -96,6 +96,17 @@ int type_count(const std::string &t) {
 
 struct View { const uint8_t *base = nullptr; size_t stride = 0; size_t count = 0; long long ct = 0; int nc = 0; bool normalized = false; };
 
+// A JSON number that must be a non-negative integer (offsets, counts, lengths, indices of untrusted files):
+// negative, fractional, non-finite or > 2^53 values are rejected instead of wrapping through a cast.
+size_t json_size(const Json &j, size_t dflt, const char *what) {
+    if (j.kind != Json::Num) return dflt;
+    const double v = j.num;
+    if (!(v >= 0.0) || v > 9007199254740992.0 || v != std::floor(v)) bad(std::string(what) + " is not a non-negative integer");
+    return (size_t)v;
+}
+// [off, off + need) inside a buffer of `size` bytes, without forming off + need
+bool in_range(size_t off, size_t need, size_t size) { return off <= size && need <= size - off; }
+
 View accessor(const Doc &d, long long idx) {
     const Json &accs = d.js.at("accessors");
     if (idx < 0 || (size_t)idx >= accs.size()) bad("accessor index out of range");
@@ -103,20 +114,29 @@ View accessor(const Doc &d, long long idx) {
     View v;
     v.ct = a.at("componentType").integer(0);
     v.nc = type_count(a.at("type").str);
-    v.count = (size_t)a.at("count").integer(0);
+    v.count = json_size(a.at("count"), 0, "accessor.count");
     v.normalized = a.at("normalized").kind == Json::Bool && a.at("normalized").b;
     const int cs = comp_size(v.ct);
     const Json *bvi = a.find("bufferView");
     if (!bvi) return v;  // zeros
     const Json &bvs = d.js.at("bufferViews");
-    if ((size_t)bvi->integer(-1) >= bvs.size()) bad("bufferView index out of range");
-    const Json &bv = bvs[(size_t)bvi->integer(0)];
-    size_t bi = (size_t)bv.at("buffer").integer(0);
+    const size_t bvn = json_size(*bvi, (size_t)-1, "accessor.bufferView");
+    if (bvn >= bvs.size()) bad("bufferView index out of range");
+    const Json &bv = bvs[bvn];
+    const size_t bi = json_size(bv.at("buffer"), 0, "bufferView.buffer");
     if (bi >= d.buffers.size()) bad("buffer index out of range");
-    size_t off = (size_t)bv.at("byteOffset").integer(0) + (size_t)a.at("byteOffset").integer(0);
-    size_t stride = (size_t)bv.at("byteStride").integer(0);
-    if (!stride) stride = (size_t)cs * v.nc;
-    if (v.count && off + (v.count - 1) * stride + (size_t)cs * v.nc > d.buffers[bi].size()) bad("accessor exceeds buffer");
+    const size_t size = d.buffers[bi].size();
+    const size_t off_bv = json_size(bv.at("byteOffset"), 0, "bufferView.byteOffset"), off_a = json_size(a.at("byteOffset"), 0, "accessor.byteOffset");
+    if (!in_range(off_bv, off_a, size)) bad("accessor exceeds buffer");
+    const size_t off = off_bv + off_a;
+    size_t stride = json_size(bv.at("byteStride"), 0, "bufferView.byteStride");
+    const size_t elem = (size_t)cs * (size_t)v.nc;
+    if (!stride) stride = elem;
+    if (v.count) {
+        size_t span;  // (count - 1) * stride + elem, overflow-checked
+        if (__builtin_mul_overflow(v.count - 1, stride, &span) || __builtin_add_overflow(span, elem, &span) || !in_range(off, span, size))
+            bad("accessor exceeds buffer");
+    }
     v.base = d.buffers[bi].data() + off;
     v.stride = stride;
     return v;
@@ -170,9 +190,13 @@ void decode_image(const Doc &d, const Json &img, Image &out) {
     const uint8_t *p = nullptr;
     size_t n = 0;
     if (const Json *bvi = img.find("bufferView")) {
-        const Json &bv = d.js.at("bufferViews")[(size_t)bvi->integer(0)];
-        size_t bi = (size_t)bv.at("buffer").integer(0), off = (size_t)bv.at("byteOffset").integer(0), len = (size_t)bv.at("byteLength").integer(0);
-        if (bi >= d.buffers.size() || off + len > d.buffers[bi].size()) bad("image bufferView out of range");
+        const Json &bvs = d.js.at("bufferViews");
+        const size_t bvn = json_size(*bvi, (size_t)-1, "image.bufferView");
+        if (bvn >= bvs.size()) bad("image bufferView index out of range");
+        const Json &bv = bvs[bvn];
+        const size_t bi = json_size(bv.at("buffer"), 0, "bufferView.buffer"), off = json_size(bv.at("byteOffset"), 0, "bufferView.byteOffset");
+        const size_t len = json_size(bv.at("byteLength"), 0, "bufferView.byteLength");
+        if (bi >= d.buffers.size() || !in_range(off, len, d.buffers[bi].size())) bad("image bufferView out of range");
         p = d.buffers[bi].data() + off; n = len;
     } else if (img.at("uri").is_str() && img.at("uri").str.rfind("data:", 0) == 0) {
         const std::string &u = img.at("uri").str;
@@ -245,12 +269,16 @@ void load(lpt_scene *scene, const uint8_t *data, size_t size) {
     const uint32_t mat_offset = (uint32_t)tmp.materials.size();
     const uint32_t texture_offset = (uint32_t)tmp.images.size();
     const Json &textures = d.js.at("textures");
+    const size_t n_images = d.js.at("images").size();
     auto tex_id = [&](const Json &info) -> uint32_t {
         if (!info.is_obj()) return LPT_INVALID_INDEX;
         size_t ti = (size_t)info.at("index").integer(-1);
         if (ti >= textures.size()) bad("texture index out of range");
         const Json *src = textures[ti].find("source");
-        return src ? texture_offset + (uint32_t)src->integer(0) : LPT_INVALID_INDEX;
+        if (!src) return LPT_INVALID_INDEX;
+        const size_t si = json_size(*src, (size_t)-1, "texture.source");
+        if (si >= n_images) bad("texture.source out of range");
+        return texture_offset + (uint32_t)si;
     };
     const Json &mats = d.js.at("materials");
     for (size_t i = 0; i < mats.size(); ++i) {

@@ -38,7 +38,14 @@ struct Json {
         return (kind == Arr && i < arr.size()) ? arr[i] : null_json;
     }
     double number(double dflt) const { return kind == Num ? num : dflt; }
-    long long integer(long long dflt) const { return kind == Num ? (long long)num : dflt; }
+    // saturating: a cast of an out-of-range or NaN double is undefined; callers range-check the result
+    long long integer(long long dflt) const {
+        if (kind != Num) return dflt;
+        if (!(num == num)) return -1;
+        if (num >= 4.0e18) return (long long)4000000000000000000LL;
+        if (num <= -4.0e18) return -(long long)4000000000000000000LL;
+        return (long long)num;
+    }
 };
 
 class JsonParser {

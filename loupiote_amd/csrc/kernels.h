@@ -154,14 +154,15 @@ template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Queue q, float4 *Lsum, FrameCounters *ctr) {
     __shared__ uint32_t lds[8];
     const uint32_t stride = gridDim.x * blockDim.x;
-    // n_slots is a multiple of 256 (tile area is), so whole blocks stay converged for the barriers
+    // the tile area is only a multiple of 64: whole blocks stay in the loop for the barriers of block_compact
     const uint32_t total = p.n_slots * p.n_samples;
-    for (uint32_t vslot = blockIdx.x * blockDim.x + threadIdx.x; vslot < total; vslot += stride) {
+    const uint32_t rounded = (total + (kBlock - 1u)) & ~(uint32_t)(kBlock - 1u);
+    for (uint32_t vslot = blockIdx.x * blockDim.x + threadIdx.x; vslot < rounded; vslot += stride) {
         const uint32_t sample = vslot / p.n_slots, slot = vslot - sample * p.n_slots;
         const uint32_t seed_counter = p.seed_counter + sample * p.max_bounces;
         uint32_t x = 0, y = 0;
-        const bool valid = slot_to_pixel(p, slot, x, y);
-        Lsum[vslot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool valid = vslot < total && slot_to_pixel(p, slot, x, y);
+        if (vslot < total) Lsum[vslot] = make_float4(0.f, 0.f, 0.f, 0.f);
         f3 d = mk3(0.f, 0.f, 0.f);
         if (valid) {
             const uint32_t pixel = y * p.width + x;
@@ -920,6 +921,36 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
             fc += k == 0u ? p.fc_inc0 : 1u;
         }
         accum[px] = a;
+    }
+}
+
+// ------------------------------------------------------------------ frame exchange (owned-tile gather)
+// A rank's owned pixels in SLOT order (tile after tile, row-major inside a tile): what travels to rank 0.  Slots of
+// edge tiles that fall outside the image carry zeros and are never read back.
+__global__ __launch_bounds__(kBlock) void k_pack_owned(FrameParams p, const float4 *accum, float4 *out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x, y;
+        out[slot] = slot_to_pixel(p, slot, x, y) ? accum[(size_t)y * p.width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+// first slot of rank `q` in the concatenation of all ranks' slot arrays: ranks own floor(n_tiles / world) tiles, the
+// first n_tiles % world of them one more (tile id mod world = owner)
+__device__ __host__ __forceinline__ uint32_t shard_slot_offset(uint32_t n_tiles, uint32_t world, uint32_t tile_area, uint32_t q) {
+    const uint32_t base = n_tiles / world, rem = n_tiles - base * world;
+    return (q * base + (q < rem ? q : rem)) * tile_area;
+}
+// rank 0: the whole frame from the concatenated slot arrays (inverse of slot_to_pixel for every owner)
+__global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const float4 *staged, float4 *frame) {
+    const uint32_t stride = gridDim.x * blockDim.x, npx = p.width * p.height;
+    const uint32_t area = p.tile_w * p.tile_h;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
+        const uint32_t y = i / p.width, x = i - y * p.width;
+        const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
+        const uint32_t tile = ty * p.tiles_x + tx;
+        const uint32_t owner = tile % p.world, k = tile / p.world;
+        const uint32_t slot = k * area + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        frame[i] = staged[(size_t)shard_slot_offset(p.n_tiles, p.world, area, owner) + slot];
     }
 }
 

@@ -1,0 +1,116 @@
+"""-m gpu: the multi-GPU frame exchange behind the C ABI (include/lpt.h "multi-GPU frame exchange").
+
+N ranks are emulated on the one GPU of the box by N sharded renderers of one process
+(lpt_renderer_exchange_local: the RCCL send / recv pairs become device copies, everything else — tile
+ownership, packing, the staging layout, the unpack on rank 0, the presented frame — is the code the
+RCCL path runs).  The RCCL calls themselves are driven through a one-rank communicator in a child
+process that never imports torch (tests/tools/comm_one_rank.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from loupiote_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(device, glb):
+    scene = lp.Scene()
+    lp.loaders.load_gltf(glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    return sg, pr
+
+
+def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8)):
+    r = lp.Renderer(device, (w, h))
+    r.downsample_factor = 1.0
+    r.resize(device, sg, pr, (w, h))
+    r.set_max_bounces(bounces)
+    r.set_vfov(T.VFOV)
+    if world > 1:
+        r.set_shard(rank, world, tile[0], tile[1])
+        r.set_resources(device, sg, pr)
+    r.reset_accumulation()
+    r.accumulate = True
+    return r
+
+
+@pytest.mark.parametrize("w,h,world,tile", [(200, 120, 2, (32, 8)), (200, 120, 3, (32, 8)), (203, 117, 2, (8, 8)), (97, 61, 5, (16, 8)), (64, 64, 8, (32, 8))])
+def test_progressive_frames_exchanged_every_frame_equal_one_gpu(device, cornell_glb, w, h, world, tile):
+    """ADVICE r1 (dist.py:38): exchange after EVERY progressive frame; rank 0's presented frame must equal the single-GPU
+    frame each time (an in-place reduce into rank 0's accumulation buffer double-counts from the second frame on).
+    Ragged sizes with 8x8 tiles exercise raygen blocks that are only partly inside the slot range (ADVICE device.hip:834)."""
+    sg, pr = _setup(device, cornell_glb)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    one = _renderer(device, sg, pr, w, h, 4)
+    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, tile) for q in range(world)]
+    for frame in range(3):
+        one.raytrace(view)
+        want = one.read_radiance()
+        want8 = one.read_pixels()
+        for r in ranks:
+            r.raytrace(view)
+        ranks[0].exchange_local(ranks[1:])
+        got = ranks[0].read_radiance()
+        assert got.tobytes() == want.tobytes(), "frame %d" % frame
+        assert ranks[0].read_pixels().tobytes() == want8.tobytes()
+        # the other ranks still present their own tiles only
+        part = ranks[1].read_radiance()
+        assert np.all(part[..., 3][want[..., 3] > 0] <= 1.0) and part[..., 3].sum() < want[..., 3].sum()
+    # ray totals: the shards partition the work
+    tot = sum(r.ray_counts().closest for r in ranks)
+    assert tot == one.ray_counts().closest
+    for r in ranks + [one]:
+        r.close()
+    pr.close()
+    sg.close()
+
+
+def test_exchange_local_rejects_incomplete_shard_sets(device, cornell_glb):
+    sg, pr = _setup(device, cornell_glb)
+    a = _renderer(device, sg, pr, 64, 64, 2, 0, 3)
+    b = _renderer(device, sg, pr, 64, 64, 2, 1, 3)
+    with pytest.raises(lp.Error) as e:
+        a.exchange_local([b])           # rank 2 is missing
+    assert e.value.kind == "InvalidArg"
+    with pytest.raises(lp.Error):
+        a.exchange_local([b, b])        # rank 1 twice
+    with pytest.raises(lp.Error):
+        b.exchange_local([a, a])        # root must be rank 0
+    for r in (a, b):
+        r.close()
+    pr.close()
+    sg.close()
+
+
+def test_exchange_without_a_communicator_is_a_noop(device, cornell_glb):
+    sg, pr = _setup(device, cornell_glb)
+    r = _renderer(device, sg, pr, 96, 64, 3)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    r.raytrace(view)
+    a = r.read_radiance()
+    r.exchange()
+    r.exchange(lp.EXCHANGE_REDUCE)
+    assert r.read_radiance().tobytes() == a.tobytes()
+    with pytest.raises(lp.Error):
+        r.exchange(7)
+    r.close()
+    pr.close()
+    sg.close()
+
+
+def test_rccl_one_rank_communicator_without_torch():
+    """lpt_comm_unique_id / lpt_comm_create / lpt_renderer_set_comm / lpt_renderer_exchange (both modes, and the denoiser
+    inputs) through ctypes in a process that never imports torch: the library links librccl itself."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "comm_one_rank.py")], env=env, capture_output=True, text=True, timeout=600)
+    print(p.stdout[-3000:], p.stderr[-3000:])
+    assert p.returncode == 0
+    assert "COMM_ONE_RANK_OK" in p.stdout

@@ -175,6 +175,50 @@ def test_parse_failures_are_file_not_found(bad):
         G.load_gltf(bad, G.Scene())
 
 
+def _hostile(mutate):
+    js = json.loads(make_gltf([[dict(pos=QUAD, nrm=QN, uv=QUV, idx=[0, 1, 2, 0, 2, 3], material=0)]], [{"mesh": 0}],
+                              [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}], images=[png_bytes(np.zeros((4, 4, 4), np.uint8))], textures=[0]))
+    mutate(js)
+    return json.dumps(js).encode()
+
+
+@pytest.mark.parametrize("mutate", [
+    lambda j: j["bufferViews"][0].__setitem__("byteOffset", -16),                       # negative offset wraps through size_t
+    lambda j: j["accessors"][0].__setitem__("byteOffset", -4),
+    lambda j: j["accessors"][0].__setitem__("byteOffset", 1.8446744073709552e19),       # 2^64: off + span wraps to a small number
+    lambda j: j["accessors"][0].__setitem__("count", 2 ** 61),                          # (count - 1) * stride overflows
+    lambda j: j["accessors"][0].__setitem__("count", -1),
+    lambda j: j["accessors"][0].__setitem__("count", 2.5),
+    lambda j: j["bufferViews"][0].__setitem__("byteStride", 2 ** 62),
+    lambda j: j["accessors"][3].__setitem__("count", 10 ** 7),                          # indices past the buffer
+    lambda j: j["accessors"][0].__setitem__("bufferView", 99),
+    lambda j: j["accessors"][0].__setitem__("bufferView", -1),
+    lambda j: j["images"][0].__setitem__("bufferView", 99),                             # was never range-checked
+    lambda j: j["images"][0].__setitem__("bufferView", -3),
+    lambda j: j["bufferViews"][4].__setitem__("byteOffset", -8),
+    lambda j: j["bufferViews"][4].__setitem__("byteLength", 1.8446744073709552e19),
+    lambda j: j["bufferViews"][4].__setitem__("byteLength", -1),
+    lambda j: j["textures"][0].__setitem__("source", 5),
+    lambda j: j["bufferViews"][0].__setitem__("buffer", 3),
+])
+def test_hostile_offsets_and_counts_are_rejected(mutate):
+    """ADVICE r1 (gltf.cpp:119,175): untrusted byteOffset / count / byteLength / indices must not wrap the bounds checks;
+    every such file is a FileNotFound and the scene stays as it was (run under ASan on the CPU build during development)"""
+    s = lp.Scene()
+    before = s.counts()
+    with pytest.raises(lp.Error) as e:
+        lp.loaders.load_gltf(_hostile(mutate), s)
+    assert e.value.kind == "FileNotFound"
+    after = s.counts()
+    assert (after.vertices, after.entries, after.images) == (before.vertices, before.entries, before.images)
+
+
+def test_hostile_baseline_still_loads():
+    s = lp.Scene()
+    lp.loaders.load_gltf(_hostile(lambda j: None), s)
+    assert s.counts().entries == 2 and s.counts().images == 1
+
+
 def test_load_gltf_path(tmp_path, cornell_glb):
     p = tmp_path / "c.glb"
     p.write_bytes(cornell_glb)

@@ -1,0 +1,73 @@
+"""Child process of tests/test_gpu_exchange.py: a ONE-rank RCCL communicator driven through the C ABI only.
+torch is never imported here — the frame exchange is plain RCCL inside libloupiote_hip.so."""
+import os
+import sys
+
+import numpy as np
+
+import loupiote_amd as lp
+from loupiote_amd import testing as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    dev = lp.Device(0)
+    glb = open(os.path.join(ROOT, "tests", "golden", "cornell-box.glb"), "rb").read()
+    scene = lp.Scene()
+    lp.loaders.load_gltf(glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, dev)
+    pr = lp.ProbeGPU(dev, T.CORNELL_PROBE, 1, 1)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    W, H = 203, 117
+
+    def mk():
+        r = lp.Renderer(dev, (W, H))
+        r.downsample_factor = 1.0
+        r.resize(dev, sg, pr, (W, H))
+        r.set_max_bounces(4)
+        r.set_vfov(T.VFOV)
+        r.reset_accumulation()
+        r.accumulate = True
+        return r
+
+    uid = lp.Comm.unique_id()
+    assert len(uid) == 128
+    comm = lp.Comm(dev, uid, 0, 1)
+    assert comm.info() == (0, 1)
+    plain, shared = mk(), mk()
+    shared.set_comm(comm)
+    shared.set_resources(dev, sg, pr)
+    shared.reset_accumulation()
+    shared.accumulate = True
+    for frame in range(3):
+        plain.raytrace(view)
+        shared.raytrace(view)
+        want = plain.read_radiance()
+        for mode in (lp.EXCHANGE_GATHER_TILES, lp.EXCHANGE_REDUCE):
+            shared.exchange(mode)
+            got = shared.read_radiance()
+            assert got.tobytes() == want.tobytes(), (frame, mode)
+    # denoising BlitMode: the exchange carries the filter inputs and rank 0 filters
+    for r in (plain, shared):
+        r.set_blit_mode(lp.BlitMode.DenoisedPathrace)
+        r.reset_accumulation()
+    for frame in range(3):
+        plain.raytrace(view)
+        shared.raytrace(view)
+        shared.exchange()
+        assert shared.read_radiance().tobytes() == plain.read_radiance().tobytes(), frame
+    assert "torch" not in sys.modules
+    shared.set_comm(None)
+    for r in (plain, shared):
+        r.close()
+    comm.close()
+    pr.close()
+    sg.close()
+    dev.close()
+    print("COMM_ONE_RANK_OK")
+
+
+if __name__ == "__main__":
+    main()
