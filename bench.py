@@ -4,18 +4,30 @@
 Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza"):
   synthetic_atrium(seed=2) — the Sponza STAND-IN (the real asset is absent) —
   1920x1080, 4 spp (= 4 raytrace() calls with accumulate), path depth 8, camera = the reference's
-  start pose.  One "step" = one such frame: reset_accumulation(); accumulate=true;
-  4 x Renderer::raytrace(view) — issued as lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 an RCCL reduce(sum) of the radiance buffer to rank 0.
+  start pose.  A FRAME = reset_accumulation(); accumulate=true; 4 x Renderer::raytrace(view) — issued as
+  lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 followed by
+  lpt_renderer_exchange (native RCCL inside the library: owned-tile gather to rank 0, or --exchange reduce).
+  A STEP = FRAMES_PER_STEP (10) such frames, so that the driver's `--steps 20` times about 2 s instead of 0.2 s.
   Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
-  Consecutive steps rotate over three renderers with their own HIP streams (--pipeline 3: three frames in flight,
-  triple buffering), so the tail of frame k (and its collective) overlaps the heads of the next frames; every step is
+  Consecutive frames rotate over three renderers with their own HIP streams (--pipeline 3: three frames in flight,
+  triple buffering), so the tail of frame k (and its exchange) overlaps the heads of the next frames; every frame is
   still one complete frame.  GPU_MAX_HW_QUEUES is raised to 8 (ROCm default 4, of which the streams here got two):
   with fewer hardware queues than streams the frames serialise again.
   N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
-  N grows ("strong" scaling of one frame).
+  N grows ("strong" scaling of one frame).  torch.distributed (gloo) is the control plane only — rendezvous of the
+  128-byte RCCL id, barriers, the max over ranks; the data path is lpt_renderer_exchange.
 
 value = (closest-hit + shadow rays traced by all ranks in the K timed steps) / wall time, in
 Mrays/s, with barrier + torch.cuda.synchronize() on both sides and the MAX over ranks.
+
+Besides `value` (a THROUGHPUT figure: three frames in flight, batched samples) the line carries
+  latency_ms  one frame alone (raytrace_n(view, 4) + synchronize), nothing else on the GPU;
+  drop_in     what the unchanged caller gets (crates/standalone, app.rs:297-318; SURVEY §8d span): ONE renderer,
+              4 x raytrace() + read_radiance() (33 MB device -> host) per frame, no raytrace_n;
+  roofline    k_trace: algorithmic bytes per launch / the UN-OVERLAPPED launch time (HIP events on the renderer's stream,
+              nothing co-running: what rocprofv3's serialised kernel trace sees) / 8 TB/s; `overlapped` = the same over the
+              timed region, where a launch shares the CUs with two other frames; `limits` = the PMC-derived ceilings;
+  cpu_baseline  the oracle ("port") on the host cores, bounded sample.
 """
 import argparse
 import json
@@ -26,6 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime at initialisation: one hardware queue per stream
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single-node control plane; the box's hostname may not resolve
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -45,14 +58,8 @@ if not os.path.exists(lp.LIB_PATH):  # the built library normally travels with t
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 4, 8
+FRAMES_PER_STEP = 10
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-class _DevBuf:
-    """exposes a raw device pointer to torch (plumbing for torch.distributed only)"""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 def cpu_baseline(desc, view, threads):
@@ -70,9 +77,25 @@ def cpu_baseline(desc, view, threads):
         secs += time.perf_counter() - t0
         rays += cnt.closest + cnt.shadow
         frames += 1
-    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "oracle/lpt_oracle.c (scalar C, pthreads, 16x16 tiles), %d of the %d spp of the same 1920x1080 depth-8 frame "
-                      "(%.1f Mrays in %.1f s)" % (frames, SPP, rays / 1e6, secs)}
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu": cpu,
+            "per_thread": rays / secs / 1e6 / max(threads, 1),
+            "sample": "oracle/lpt_oracle.c (scalar C, persistent pthread pool, SAH BVH2, 16x16 tiles), %d of the %d spp of the same 1920x1080 depth-8 frame "
+                      "(%.1f Mrays in %.1f s); a reported baseline, not a target" % (frames, SPP, rays / 1e6, secs)}
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -82,19 +105,22 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency / drop_in / solo measurements (experiments)")
     ap.add_argument("--scene", default="atrium")
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
     ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
-    ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, reduce) even with one rank")
-    ap.add_argument("--exchange", choices=["reduce", "gather"], default="reduce",
-                    help="frame exchange for N>1: dense RCCL reduce of the accumulation buffer (north star) or a gather of owned tiles only")
-    ap.add_argument("--pipeline", type=int, default=3, help="renderers (each with its own HIP stream) that take consecutive steps in turn")
+    ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, communicator, exchange) even with one rank")
+    ap.add_argument("--exchange", choices=["gather", "reduce"], default="gather",
+                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv) or the dense ncclReduce of the accumulation buffer")
+    ap.add_argument("--pipeline", type=int, default=3, help="renderers (each with its own HIP stream) that take consecutive frames in turn")
     ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
     args = ap.parse_args()
     WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
     BATCH = not args.no_batch
+    FPS = max(1, args.frames_per_step)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,41 +133,43 @@ def main():
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only (id rendezvous, barriers, max over ranks)
 
     dev = lp.Device(local_rank)
+    comm = None
+    if use_dist:
+        box = [lp.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = lp.Comm(dev, box[0], rank, world)   # ncclCommInitRank inside the library (RCCL over xGMI)
+    xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
     desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"))
     scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, dev, gpu_build=bool(os.environ.get("LPT_BENCH_GPU_BUILD")))
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
     P = max(1, args.pipeline)
-    rs, exts, accums, frames = [], [], [], []
-    for _ in range(P):
+
+    def make_renderer():
         rr = lp.Renderer(dev, (WIDTH, HEIGHT))
         rr.downsample_factor = 1.0
         rr.resize(dev, sg, probe, (WIDTH, HEIGHT))
         rr.set_max_bounces(DEPTH)
         rr.set_vfov(T.VFOV)
-        if world > 1 or args.emulate_shard > 1:
-            rr.set_shard(rank, max(world, args.emulate_shard), 32, 8)
+        if comm is not None:
+            rr.set_comm(comm)                      # = set_shard(rank, world, 32, 8) + the binding
             rr.set_resources(dev, sg, probe)
-        rs.append(rr)
-        exts.append(torch.cuda.ExternalStream(rr.stream(), device=torch.device("cuda", local_rank)))
-        ptr, nbytes = rr.radiance_device_ptr()
-        accums.append(torch.as_tensor(_DevBuf(ptr, nbytes), device=torch.device("cuda", local_rank)))
-        frames.append(torch.empty_like(accums[-1]) if use_dist else None)
-    gathers = None
-    if use_dist and args.exchange == "gather":
-        from loupiote_amd.dist import OwnedTileGather
-        gathers = [OwnedTileGather(WIDTH, HEIGHT, rank, world, device=torch.device("cuda", local_rank)) for _ in range(P)]
-    r = rs[0]
-    step_no = [0]
+        elif args.emulate_shard > 1:
+            rr.set_shard(0, args.emulate_shard, 32, 8)
+            rr.set_resources(dev, sg, probe)
+        return rr
 
-    def step():
-        k = step_no[0] % P
-        step_no[0] += 1
-        r = rs[k]
+    rs = [make_renderer() for _ in range(P)]
+    frame_no = [0]
+
+    def frame(r=None):
+        if r is None:
+            r = rs[frame_no[0] % P]
+            frame_no[0] += 1
         r.reset_accumulation()
         r.accumulate = True
         if BATCH:
@@ -149,19 +177,18 @@ def main():
         else:
             for _ in range(SPP):
                 r.raytrace(view)
-        if use_dist:
-            # radiance reduce over xGMI: ordered after this renderer's stream, which its next
-            # frame's kernels in turn wait on (torch issues the RCCL op relative to the stream)
-            with torch.cuda.stream(exts[k]):
-                if gathers is not None:
-                    gathers[k](accums[k].view(HEIGHT, WIDTH, 4))   # owned pixels only (W*H/N * 16 B per rank)
-                else:
-                    frames[k].copy_(accums[k], non_blocking=True)
-                    dist.reduce(frames[k], dst=0, op=dist.ReduceOp.SUM)
+        if comm is not None:
+            r.exchange(xmode)            # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
+
+    def step():
+        for _ in range(FPS):
+            frame()
 
     def fence():
         if use_dist:
             dist.barrier()
+        for rr in rs:
+            rr.synchronize()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -186,28 +213,24 @@ def main():
         c_ = rr.ray_counts()
         closest_l += c_.closest; shadow_l += c_.shadow; shaded_l += c_.shaded
 
-    class _C:
-        closest, shadow, shaded = closest_l, shadow_l, shaded_l
-    counts = _C
-
-    tl = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([counts.closest, counts.shadow, counts.shaded], dtype=torch.float64, device="cuda")
+    tl = torch.tensor([elapsed], dtype=torch.float64)
+    rays = torch.tensor([closest_l, shadow_l, shaded_l], dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tl.item())
     closest, shadow, shaded = [float(x) for x in rays.tolist()]
+    n_frames = args.steps * FPS
 
-    # ---- roofline of the dominant kernel (k_trace), rank 0: algorithmic bytes per launch
+    # ---- roofline of the dominant kernel (k_trace), this rank: algorithmic bytes per launch
     # = closest rays * (32 B ray read + 16 B hit write + N*80 B nodes + T*48 B triangles)
     # + shadow rays * (32 B ray read + 4 B + Ns*80 B + Ts*48 B), with N, T, Ns, Ts (mean nodes visited /
-    # triangles tested per ray) measured by the stats variant of the same kernel on the same frames,
+    # triangles tested per ray) measured by the stats variant of the same kernel on the same frame,
     # outside the timed region.
     r = rs[0]
-    step_no[0] = 0
     r.enable_stats(True)
     r.reset_ray_counts()
-    step()
+    frame(r)
     fence()
     st = r.ray_counts()
     r.enable_stats(False)
@@ -216,40 +239,68 @@ def main():
     ns_bar = st.shadow_nodes / max(st.shadow, 1)
     ts_bar = st.shadow_tris / max(st.shadow, 1)
     accel = sg.stats()
-    # dominant kernel: k_trace (closest-hit rays of bounce b+1 and shadow rays of bounce b in one persistent launch;
-    # stages "intersection" = launches that carry closest-hit rays, "shadow" = the last, shadow-only launch)
     b_ray = 32.0 + 16.0 + n_bar * accel.node_bytes + t_bar * accel.tri_bytes
     b_sh = 32.0 + 4.0 + ns_bar * accel.node_bytes + ts_bar * accel.tri_bytes
 
     def trace_stage(tm, cl, sh):
+        # stages "intersection" = k_trace launches that carry closest-hit rays, "shadow" = the last, shadow-only launch
         ms = tm.get("intersection", (0.0, 0))[0] + tm.get("shadow", (0.0, 0))[0]
         launches = tm.get("intersection", (0.0, 0))[1] + tm.get("shadow", (0.0, 0))[1]
         avg = ms / max(launches, 1)
         byts = (cl * b_ray + sh * b_sh) / max(launches, 1)
         return avg, launches, byts, (byts / (avg * 1e-3) / 1e9 if avg > 0 else 0.0)
 
-    avg_ms, i_launches, bytes_per_launch, achieved = trace_stage(timings, counts.closest, counts.shadow)
-    rays_per_launch = (counts.closest + counts.shadow) / max(i_launches, 1)
-    # the same kernel with nothing co-running (one extra untimed step on renderer 0): with --pipeline 2 the
-    # kernels of two frames share the chip, which lengthens each launch although the step gets shorter
+    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l, shadow_l)
+    rays_per_launch = (closest_l + shadow_l) / max(o_launches, 1)
+    extras = not args.no_extras
+    # the same launches with nothing co-running: SOLO_FRAMES frames on renderer 0 alone (HIP events on its stream)
+    SOLO_FRAMES = 3
     r.reset_ray_counts()
     r.enable_timings(True)
-    step_no[0] = 0
-    step()
-    fence()
+    for _ in range(SOLO_FRAMES):
+        frame(r)
+        fence()
     solo_t = r.timings()
     r.enable_timings(False)
     sc_ = r.ray_counts()
-    s_avg, s_launches, _, solo = trace_stage(solo_t, sc_.closest, sc_.shadow)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_trace_bytes_per_launch")
-        except Exception:
-            traffic = None
+    s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest, sc_.shadow)
+
+    latency = drop_in = None
+    if extras:
+        # ---- latency: one frame alone, host call to completion
+        lat = []
+        for _ in range(7):
+            fence()
+            t1 = time.perf_counter()
+            frame(r)
+            r.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        latency = {"min": lat[0], "median": lat[len(lat) // 2], "frames": len(lat),
+                   "what": "one frame alone: reset_accumulation + raytrace_n(view, 4)%s + stream synchronize" % (" + exchange" if comm is not None else "")}
+        # ---- drop-in: the unchanged caller's protocol on ONE renderer (SURVEY §8d span: raytrace() x spp ... read_radiance())
+        if comm is None and args.emulate_shard <= 1:
+            DROP_FRAMES = 10
+            fence()
+            r.reset_ray_counts()
+            t1 = time.perf_counter()
+            for _ in range(DROP_FRAMES):
+                r.reset_accumulation()
+                r.accumulate = True
+                for _ in range(SPP):
+                    r.raytrace(view)
+                img = r.read_radiance()          # blocking; 33 MB device -> host inside the span
+            dt = time.perf_counter() - t1
+            dc = r.ray_counts()
+            drop_in = {"ms_per_frame": dt / DROP_FRAMES * 1e3, "value": (dc.closest + dc.shadow) / dt / 1e6, "unit": "Mrays/s", "frames": DROP_FRAMES,
+                       "what": "ONE renderer / one stream, per frame: reset_accumulation; 4 x raytrace(view) (no raytrace_n); read_radiance() "
+                               "(k_resolve + 33 MB D2H into pageable host memory) — the span SURVEY §8d defines and crates/standalone issues (app.rs:297-318); "
+                               "GPU_MAX_HW_QUEUES has no effect with a single stream",
+                       "checksum": float(np.float64(img[..., :3].sum()))}
 
     if rank == 0:
+        traffic_j = load_profile_json("traffic.json") or {}
+        limits_j = load_profile_json("limits.json")
         out = {
             "metric": "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza; 1/2/4/8 GPU",
             "value": (closest + shadow) / elapsed / 1e6,
@@ -264,20 +315,35 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in, 262144 tris], 1920x1080, 4 spp, depth 8, "
-                                   "camera (-10,1,0)->(1,0.35,0); step = 1 frame (raytrace_n(view,4) == 4 x raytrace, + reduce)",
-                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": args.exchange if use_dist else "none", "rays_per_step": (closest + shadow) / args.steps,
+                                   "camera (-10,1,0)->(1,0.35,0); frame = raytrace_n(view,4) == 4 x raytrace%s; step = %d frames, %d frames in flight "
+                                   "(throughput; see latency_ms and drop_in for one frame alone / the unbatched protocol with read-back)"
+                                   % (" + lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", FPS, P),
+                       "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed,
+                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
+                       "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
-            "ms_per_frame": elapsed / args.steps * 1e3,
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": i_launches, "frames_in_flight": P,
-                         "solo": {"achieved": solo, "frac": solo / HBM_PEAK_GBS, "avg_launch_ms": s_avg, "launches": s_launches}, "rays_per_launch": rays_per_launch,
-                         "note": "avg_launch_ms / achieved / frac: HIP events around every k_trace launch of the timed region; with several frames in flight they include the time a launch shares or waits for the CUs (rocprofv3 serialises kernels, so its per-kernel average matches `solo`, the same kernel with nothing co-running)",
-                         "bytes_per_launch": bytes_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
+            "ms_per_frame": elapsed / n_frames * 1e3,
+            "latency_ms": latency,
+            "drop_in": drop_in,
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": s_achieved / HBM_PEAK_GBS,
+                         "traffic": traffic_j.get("k_trace_bytes_per_launch"), "traffic_source": traffic_j.get("source"),
+                         "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": s_bytes,
+                         "basis": "un-overlapped launches: %d frames on one renderer with nothing co-running, HIP events on its stream around every k_trace launch — "
+                                  "the duration rocprofv3's kernel trace reports for the same launches (profiles/, *_solo_kernel_stats.csv)" % SOLO_FRAMES,
+                         "overlapped": {"achieved": o_achieved, "frac": o_achieved / HBM_PEAK_GBS, "avg_launch_ms": o_avg, "launches": o_launches, "bytes_per_launch": o_bytes,
+                                        "frames_in_flight": P,
+                                        "note": "the timed region: HIP events around every k_trace launch while %d frames share the chip; a launch then also counts the time it "
+                                                "waits for, or shares, the CUs — a scheduling figure, not a kernel figure" % P},
+                         "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
+                                    "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation): a lower bound"},
+                         "limits": limits_j,
+                         "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
-            "stage_ms_per_step": {k: v[0] / args.steps for k, v in timings.items()},
+            "stage_ms_per_frame": {k: v[0] / n_frames for k, v in timings.items()},
+            "stage_ms_per_frame_solo": {k: v[0] / SOLO_FRAMES for k, v in solo_t.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
         }
@@ -289,9 +355,12 @@ def main():
         out = None
     if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
     for rr in rs:
         rr.close()
+    if comm is not None:
+        comm.close()
+    if use_dist:
+        dist.destroy_process_group()
     probe.close()
     sg.close()
     dev.close()

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""usage: limits_from_pmc.py <tag> <prof dir>   (run by tools/profile.sh on the GPU box)
+
+Reduces the round's rocprofv3 passes to the two small files bench.py attaches to its JSON line:
+  traffic.json : fabric-side bytes per k_trace / k_shade launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction of
+                 /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE tallies 128-B requests at 64 B; both in KiB)
+  limits.json  : what bounds k_trace, each as a fraction of its own ceiling:
+     valu_issue   wave-level VALU instructions (SQ_INSTS_VALU) x issue cycles per instruction / (SIMDs x kernel cycles);
+                  issue cycles from tools/microbench/valu_rate.hip: 1/0.39 for v_fma/mul/add/sub/and/add_u32/mov,
+                  1/0.23 for everything else; the static split of the k_trace loop (ISA of the node test) is 36 % / 64 %
+     gather_path  bytes gathered per launch (nodes + triangles, the algorithmic figure) / launch time, against the
+                  9.7-13.5 TB/s a fully divergent dwordx4 gather sustains (tools/microbench/gather_rate.hip)
+     fabric       traffic.json bytes / launch time / 8 TB/s
+     tcc_hit      TCC_HIT / (TCC_HIT + TCC_MISS)
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+CLOCK_HZ = 2.4e9      # MI355X peak engine clock
+SIMDS = 256 * 4
+FAST_RATE, SLOW_RATE = 0.39, 0.23   # wave-instructions per cycle per SIMD (valu_rate.hip)
+FAST_SHARE = 0.36                   # of k_trace's VALU instructions (85 fast + 150 slow per node visit)
+GATHER_TBS = (9.7, 13.5)
+
+
+def short(name):
+    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+
+
+def main(tag, out):
+    agg = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(set)
+    for dirpath, _, files in os.walk(out):
+        for f in files:
+            if f.endswith("counter_collection.csv"):
+                for row in csv.DictReader(open(os.path.join(dirpath, f))):
+                    k = short(row["Kernel_Name"])
+                    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                    launches[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
+
+    def per_launch(k, c):
+        n = len(launches[(k, c)])
+        return agg[k][c] / n if n else None
+
+    solo = {}
+    p = os.path.join(out, tag + "_solo_kernel_stats.csv")
+    if os.path.exists(p):
+        for row in csv.DictReader(open(p)):
+            solo[short(row["Name"])] = (float(row["AverageNs"]), int(row["Calls"]))
+    bench = {}
+    p = os.path.join(out, tag + "_solo_bench.json")
+    if os.path.exists(p):
+        try:
+            bench = json.loads(open(p).read().strip())
+        except Exception:
+            bench = {}
+    traffic = {"_comment": "fabric-side bytes per launch from rocprofv3 --pmc (separate passes, tools/profile.sh): FETCH_SIZE (KiB; gfx950 tallies 128-B requests at "
+                           "64 B, so doubled, MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KiB).  The BVH is L2 / Infinity-Cache resident: this is fabric traffic, not "
+                           "necessarily DRAM traffic.", "round": tag, "source": "profiles/traffic.json@" + tag}
+    for k, key in (("k_trace<false>", "k_trace"), ("k_shade<false>", "k_shade")):
+        f, w = per_launch(k, "FETCH_SIZE"), per_launch(k, "WRITE_SIZE")
+        if f is not None and w is not None:
+            traffic[key + "_fetch_kib_per_launch"] = f
+            traffic[key + "_write_kib_per_launch"] = w
+            traffic[key + "_bytes_per_launch"] = int((2.0 * f + w) * 1024)
+            traffic[key + "_launches_profiled"] = len(launches[(k, "FETCH_SIZE")])
+    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+
+    lim = {"round": tag, "source": "profiles/limits.json@" + tag, "kernel": "k_trace<false>", "clock_hz": CLOCK_HZ}
+    k = "k_trace<false>"
+    avg_ns = solo.get(k, (None, 0))[0]
+    if avg_ns:
+        lim["solo_avg_launch_ms_rocprof"] = avg_ns / 1e6
+        cycles = avg_ns * 1e-9 * CLOCK_HZ
+        v = per_launch(k, "SQ_INSTS_VALU")
+        if v:
+            issue = v * (FAST_SHARE / FAST_RATE + (1 - FAST_SHARE) / SLOW_RATE)
+            lim["valu_issue"] = {"frac": issue / (SIMDS * cycles), "valu_wave_insts_per_launch": v, "fast_share": FAST_SHARE,
+                                 "rates_inst_per_clk_per_simd": [FAST_RATE, SLOW_RATE]}
+        r = bench.get("roofline", {})
+        if r.get("bytes_per_launch"):
+            gb = r["bytes_per_launch"] - r.get("rays_per_launch", 0) * 48.0   # nodes + triangles only
+            tbs = gb / (avg_ns * 1e-9) / 1e12
+            lim["gather_path"] = {"tb_per_s": tbs, "frac_of_13.5": tbs / GATHER_TBS[1], "frac_of_9.7": tbs / GATHER_TBS[0], "ceiling_tb_per_s": list(GATHER_TBS)}
+        if "k_trace_bytes_per_launch" in traffic:
+            lim["fabric"] = {"bytes_per_launch": traffic["k_trace_bytes_per_launch"], "frac": traffic["k_trace_bytes_per_launch"] / (avg_ns * 1e-9) / 8e12}
+    h, m = per_launch(k, "TCC_HIT_sum"), per_launch(k, "TCC_MISS_sum")
+    if h is not None and m is not None and h + m > 0:
+        lim["tcc_hit"] = h / (h + m)
+    k2 = "k_shade<false>"
+    h, m = per_launch(k2, "TCC_HIT_sum"), per_launch(k2, "TCC_MISS_sum")
+    if h is not None and m is not None and h + m > 0:
+        lim["k_shade_tcc_hit"] = h / (h + m)
+    wv, wc, bc = per_launch(k, "SQ_WAVES"), per_launch(k, "SQ_WAVE_CYCLES"), per_launch(k, "SQ_BUSY_CYCLES")
+    if wv:
+        lim["waves_per_launch"] = wv
+    json.dump(lim, open(os.path.join(out, "limits.json"), "w"), indent=1)
+    print(json.dumps(lim, indent=1))
+    print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
