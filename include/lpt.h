@@ -421,6 +421,13 @@ int lpt_renderer_exchange(lpt_renderer *r, int mode);
  * on other devices of the process).  Used by single-process hosts and by the tests that emulate N ranks on one GPU. */
 int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers);
 
+/* new (north star: "a sorted shade / next-event stage using wavefront ballot / prefix-sum"; the reference dispatches the
+ * full pixel grid unsorted, renderer.rs:484-509).  flag != 0: the shading pass writes the next-bounce and the shadow-ray
+ * queue ordered by direction octant inside every 256-ray block (ballot + popcount per key, LDS prefix sum, still one
+ * atomic per block), so a traversal wave's 64 rays share one or two octants.  Results are keyed by pixel slot and do
+ * not change by a bit; only traversal coherence does.  flag: 1 = next-bounce queue only, 2 = shadow queue only, 3 (or any
+ * other non-zero value) = both.  Default: off (measured slower on the bench scene). */
+int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
 /* per-bounce queue sizes of the LAST traced frame: closest[b] = closest-hit rays of bounce b, shadow[b] = shadow rays
  * emitted by bounce b; up to `cap` entries each (either pointer may be NULL).  Blocking. */

@@ -422,6 +422,10 @@ class Renderer:
         arr = (C.c_void_p * max(len(peers), 1))(*[p._h for p in peers])
         _check(A.lib().lpt_renderer_exchange_local(self._h, arr, len(peers)))
 
+    def set_sort_queues(self, flag):
+        """the shading pass emits both ray queues ordered by direction octant inside each block (bit-identical results)"""
+        _check(A.lib().lpt_renderer_set_sort_queues(self._h, int(flag)))
+
     def queue_counts(self, n=64):
         """per-bounce (closest-hit, shadow) queue sizes of the last traced frame"""
         c, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)

@@ -91,6 +91,7 @@ struct lpt_renderer {
     bool use_noise = false, stats = false, timings = false;
     // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
     int refill = 44;
+    int sort_queues = 0;       // k_shade emits both ray queues ordered by direction octant within a block (lpt_renderer_set_sort_queues / LPT_SORT)
     bool merge_trace = true;
     uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
     uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_WAVES_PER_CU pins it
@@ -792,6 +793,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     }
     if (const char *ev = getenv("LPT_SHADE_BLOCKS_PER_CU")) r->shade_blocks_per_cu = (uint32_t)std::max(1, std::min(64, atoi(ev)));
     if (const char *ev = getenv("LPT_MERGE_TRACE")) r->merge_trace = atoi(ev) != 0;
+    if (const char *ev = getenv("LPT_SORT")) r->sort_queues = atoi(ev) & 3;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
@@ -934,6 +936,11 @@ int lpt_renderer_use_noise(lpt_renderer *r, int flag) {
 int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode) {
     if (!r || mode < LPT_BLIT_PATHTRACE || mode > LPT_BLIT_MOTION) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_blit_mode: bad mode %d", mode);
     r->mode = mode;
+    return LPT_OK;
+}
+int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_sort_queues: null");
+    r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;   // 1: next-bounce queue, 2: shadow queue, 3 (or any other non-zero): both
     return LPT_OK;
 }
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
@@ -1135,9 +1142,9 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
             }
             stage_begin(r, ST_SHADE);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
-                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb, r->sort_queues);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb);
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb, r->sort_queues);
             stage_end(r);
             if (r->merge_trace) {
                 trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);

@@ -133,6 +133,42 @@ __device__ __forceinline__ uint32_t block_compact(bool valid, uint32_t *counter,
     return idx;
 }
 
+// Sorted variant of block_compact (the "sorted shade / next-event stage" of the north star): the block's valid
+// elements are written in KEY order (8 keys: the direction octant of the ray), so that the 64 consecutive rays a
+// traversal wave pulls share one or two octants instead of eight.  Per wave and key one ballot + popcount, the
+// (key, wave) counts are prefix-summed in LDS (key-major), still ONE global atomic per block and counter.
+// Results are keyed by pixel slot, so the order of a queue never changes them.  `lds` needs 72 uint32.
+__device__ __forceinline__ uint32_t block_compact_binned(bool valid, uint32_t key, uint32_t *counter, uint32_t *lds) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long mine = 0ull;
+    uint32_t cnt_k = 0;  // lane k < 8 keeps this wave's count of key k
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const unsigned long long m = __ballot(valid && key == k);
+        if (key == k) mine = m;
+        if (lane == k) cnt_k = (uint32_t)__popcll(m);
+    }
+    if (lane < 8u) lds[lane * 4u + wave] = cnt_k;   // [key][wave]
+    __syncthreads();
+    if (threadIdx.x < 32u) {
+        // exclusive prefix over the 32 (key, wave) cells in key-major order: one wave32-style shuffle scan
+        const uint32_t c = lds[threadIdx.x];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        lds[32u + threadIdx.x] = incl - c;
+        if (threadIdx.x == 31u) lds[64u] = incl ? atomicAdd(counter, incl) : 0u;
+    }
+    __syncthreads();
+    const uint32_t idx = lds[64u] + lds[32u + key * 4u + wave] + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    __syncthreads();  // lds is reused by the next call
+    return idx;
+}
+__device__ __forceinline__ uint32_t dir_octant(float x, float y, float z) { return (x < 0.0f ? 1u : 0u) | (y < 0.0f ? 2u : 0u) | (z < 0.0f ? 4u : 0u); }
+
 __device__ __forceinline__ void noise_shift(const DNoise &nz, uint32_t x, uint32_t y, uint32_t seed_counter, float &r0, float &r1) {
     if (!nz.enabled) return;
     const uint8_t *t = nz.rgba + 4u * ((size_t)(y % nz.h) * nz.w + (x % nz.w));
@@ -736,8 +772,8 @@ struct GBufArgs { uint4 *gbuf; float2 *motion; CamBasis cur, prev; };
 template <bool GBUF>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
-                                                  uint32_t seed_base, GBufArgs gb) {
-    __shared__ uint32_t lds[8];
+                                                  uint32_t seed_base, GBufArgs gb, int sorted) {
+    __shared__ uint32_t lds[72];
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];  // kBlock == 256
     __syncthreads();
@@ -892,10 +928,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                 gb.motion[px] = make_float2(mu, mv);
             }
         }
-        const uint32_t si = block_compact(want_shadow, &ctr->shcount[bounce], lds);
+        // `sorted` (wave-uniform; bit 0: next-bounce queue, bit 1: shadow queue): the queue leaves the block ordered by direction octant
+        const uint32_t si = (sorted & 2) ? block_compact_binned(want_shadow, want_shadow ? dir_octant(sd4.x, sd4.y, sd4.z) : 0u, &ctr->shcount[bounce], lds)
+                                   : block_compact(want_shadow, &ctr->shcount[bounce], lds);
         if (want_shadow) { st_nt(sq.o + si, so4); st_nt(sq.d + si, sd4); st_nt(sq.c + si, sc4); }
         if (!last_bounce) {
-            const uint32_t ni = block_compact(want_next, &ctr->qcount[bounce + 1], lds);
+            const uint32_t ni = (sorted & 1) ? block_compact_binned(want_next, want_next ? dir_octant(nd4.x, nd4.y, nd4.z) : 0u, &ctr->qcount[bounce + 1], lds)
+                                       : block_compact(want_next, &ctr->qcount[bounce + 1], lds);
             if (want_next) { st_nt(qout.o + ni, no4); st_nt(qout.d + ni, nd4); st_nt(qout.T + ni, nT4); }
         }
         n_surface += is_surface ? 1u : 0u;

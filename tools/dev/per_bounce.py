@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import loupiote_amd as lp  # noqa: E402
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
-W, H, SPP, DEPTH = 1920, 1080, 4, 8
+W, H, SPP, DEPTH = 1920, 1080, int(os.environ.get("PB_SPP", "4")), 8
 dev = lp.Device(0)
 desc = scenes.synthetic_atrium()
 sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), dev)
