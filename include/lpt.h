@@ -114,6 +114,9 @@ typedef struct lpt_accel_stats {
     uint32_t tri_bytes;  /* bytes per pre-transformed triangle          */
     uint32_t max_depth;
     float build_ms;
+    uint32_t host_baked_triangles; /* triangles transformed to world space on the HOST by the last upload (0 for
+                                      LPT_ACCEL_BUILD_GPU_LBVH: instances are baked by k_bake_instance on the device) */
+    float upload_ms;               /* wall time of the whole lpt_scene_upload(_ex) call: bake + build + copies */
 } lpt_accel_stats;
 
 /* result of a closest-hit query (the build's `Intersection`, 16 bytes) */
@@ -253,7 +256,9 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
 /* new (the reference builds its BVH on the CPU at load time, loaders/gltf.rs:97-105): the same upload with
  * a choice of builder.  LPT_ACCEL_BUILD_HOST_SAH = binned-SAH + SAH-optimal 8-wide collapse on the host (what
  * lpt_scene_upload does); LPT_ACCEL_BUILD_GPU_LBVH = Morton-code radix tree collapsed to 8-wide nodes on the GPU
- * (a few milliseconds; lower tree quality) for scenes that are rebuilt every frame.  Rendered results are identical. */
+ * (a few milliseconds; lower tree quality) for scenes that are rebuilt every frame; with it the instances are also baked
+ * on the device (object-space meshes + one transform per instance travel, nothing else is computed on the host).
+ * Rendered results are identical. */
 #define LPT_ACCEL_BUILD_HOST_SAH 0u
 #define LPT_ACCEL_BUILD_GPU_LBVH 1u
 int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags, lpt_scene_gpu **out);

@@ -279,22 +279,6 @@ Box padded_box(const lpt_vertex *v) {
 
 }  // namespace
 
-int bake_only(const lpt_scene &scene, Accel &out) {
-    bake(scene, out);
-    const size_t n = out.tri_material.size();
-    out.nodes.clear();
-    out.leaf_prim.clear();
-    out.level_start.clear();
-    out.max_depth = 0;
-    if (n >= (1u << 29)) return fail(LPT_ERR_ACCEL_BUILD, "too many triangles (%zu)", n);
-    for (size_t k = 0; k < out.tri_verts.size(); ++k)
-        for (int a = 0; a < 3; ++a)
-            if (!std::isfinite(out.tri_verts[k].position[a])) return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in baked triangle %zu", k / 3);
-    out.woop.resize(n);
-    for (size_t t = 0; t < n; ++t) woop_from_triangle(out.tri_verts[3 * t].position, out.tri_verts[3 * t + 1].position, out.tri_verts[3 * t + 2].position, out.woop[t]);
-    return LPT_OK;
-}
-
 int bake_and_build(const lpt_scene &scene, Accel &out) {
     const auto t0 = std::chrono::steady_clock::now();
     bake(scene, out);

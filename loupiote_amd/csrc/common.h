@@ -68,8 +68,6 @@ struct Accel {
 
 // bvh.cpp
 int bake_and_build(const lpt_scene &scene, Accel &out);
-// baking only (for the GPU builder): tri_verts, tri_material, inst_first/count and the Woop maps in PRIM order
-int bake_only(const lpt_scene &scene, Accel &out);
 void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3], WoopTri &w);
 
 // png.cpp

@@ -368,14 +368,32 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     if (!dev || !scene || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload: null");
     if (flags > LPT_ACCEL_BUILD_GPU_LBVH) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload_ex: unknown flags %u", flags);
     HIP_TRY(hipSetDevice(dev->ordinal));
+    const auto t_upload = std::chrono::steady_clock::now();
     Accel acc;
     bool gpu_build = flags == LPT_ACCEL_BUILD_GPU_LBVH;
-    int st = gpu_build ? bake_only(*scene, acc) : bake_and_build(*scene, acc);
-    if (st != LPT_OK) return st;
-    if (gpu_build && acc.tri_material.size() < 16) {  // tiny scenes: the host builder (a radix tree needs >= 2 leaves)
-        gpu_build = false;
+    uint32_t n_tris = 0;
+    int st = LPT_OK;
+    if (gpu_build) {
+        // layout only: which run of baked triangles every instance owns (SPEC §2.5 order).  No vertex is touched on the
+        // host; the instances are baked on the device below (k_bake_instance)
+        acc.inst_first.assign(scene->instances.size(), 0u);
+        acc.inst_count.assign(scene->instances.size(), 0u);
+        size_t total = 0;
+        for (size_t i = 0; i < scene->instances.size(); ++i) {
+            const lpt_instance &in = scene->instances[i];
+            const uint32_t cnt = in.blas_index < scene->entries.size() ? scene->entries[in.blas_index].index_count / 3u : 0u;
+            acc.inst_first[i] = (uint32_t)total;
+            acc.inst_count[i] = cnt;
+            total += cnt;
+        }
+        if (total >= (1u << 29)) return fail(LPT_ERR_ACCEL_BUILD, "too many triangles (%zu)", total);
+        n_tris = (uint32_t)total;
+        if (n_tris < 16u) gpu_build = false;   // tiny scenes: the host builder (a radix tree needs >= 2 leaves)
+    }
+    if (!gpu_build) {
         st = bake_and_build(*scene, acc);
         if (st != LPT_OK) return st;
+        n_tris = (uint32_t)acc.tri_material.size();
     }
     lpt_scene_gpu *sg = new lpt_scene_gpu();
     sg->dev = dev;
@@ -385,20 +403,22 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
         lpt_scene_gpu_destroy(sg);                                             \
         return st;                                                             \
     }
+    static_assert(sizeof(float4) * kTriRec == 128 && sizeof(lpt_vertex) * 3 == 96 && sizeof(lpt_material) == 32, "shading record layout");
     if (!gpu_build) {
         UP(nodes, acc.nodes)
         UP(woop, acc.woop)
         UP(leaf_prim, acc.leaf_prim)
-    }
-    {   // shading records (kernels.h DScene::tri_verts): three vertices + the material, 128 B per triangle
+        // shading records (kernels.h DScene::tri_verts): three vertices + the material, 128 B per triangle
         struct TriRec { float4 v[kTriRec]; };
-        static_assert(sizeof(TriRec) == 128 && sizeof(lpt_vertex) * 3 == 96 && sizeof(lpt_material) == 32, "shading record layout");
         std::vector<TriRec> recs(acc.tri_material.size());
         for (size_t t = 0; t < recs.size(); ++t) {
             memcpy(recs[t].v, &acc.tri_verts[3 * t], 96);
             memcpy(&recs[t].v[6], &scene->materials[acc.tri_material[t] < scene->materials.size() ? acc.tri_material[t] : 0], 32);
         }
         UP(tri_verts, recs)
+    } else {
+        hipError_t e = hipMalloc(&sg->tri_verts, sizeof(float4) * kTriRec * (size_t)n_tris);   // written by k_bake_instance
+        if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
     }
     UP(materials, scene->materials)
     UP(lights, scene->lights)
@@ -458,7 +478,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     d.texels = (const uint8_t *)sg->texels;
     d.images = (const DImage *)sg->images;
     d.srgb_lut = (const float *)sg->srgb_lut;
-    d.n_tris = (uint32_t)acc.tri_material.size();
+    d.n_tris = n_tris;
     d.n_materials = (uint32_t)scene->materials.size();
     d.n_lights = (uint32_t)scene->lights.size();
     d.n_images = (uint32_t)scene->images.size();
@@ -468,11 +488,35 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     sg->stats.tri_bytes = (uint32_t)sizeof(WoopTri);
     sg->stats.max_depth = acc.max_depth;
     sg->stats.build_ms = acc.build_ms;
+    sg->stats.host_baked_triangles = gpu_build ? 0u : n_tris;
     if (gpu_build) {
-        st = build_lbvh(sg, (uint32_t)acc.tri_material.size(), acc.woop.data(), nullptr, s);
+        // bake every instance on the device (fp32 transform, cofactor normals, binary64 Woop maps: bit-identical to the
+        // host bake), then build the tree there
+        void *woop_prim = nullptr;
+        e = hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)n_tris);
+        if (e != hipSuccess) { lpt_scene_gpu_destroy(sg); return fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e)); }
+        for (size_t i = 0; i < scene->instances.size() && st == LPT_OK; ++i) {
+            const uint32_t first = sg->inst_first[i], cnt = sg->inst_count[i];
+            if (!cnt) continue;
+            BakeArgs a;
+            st = make_bake_args(*scene, i, first, cnt, a);
+            if (st == LPT_OK)
+                hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
+                                   (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
+        }
+        uint32_t bad = 0;
+        if (st == LPT_OK) {
+            e = hipMemcpyAsync(&bad, sg->bad_flag, sizeof bad, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) st = fail(LPT_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e));
+            else if (bad) st = fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in a baked triangle");
+        }
+        if (st == LPT_OK) st = build_lbvh(sg, n_tris, nullptr, (const float4 *)woop_prim, s);
+        hipFree(woop_prim);
         if (st != LPT_OK) { lpt_scene_gpu_destroy(sg); return st; }
         d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
     }
+    sg->stats.upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_upload).count();
     *out = sg;
     return LPT_OK;
 }

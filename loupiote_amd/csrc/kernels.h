@@ -52,7 +52,10 @@ struct DScene {
 struct DProbe { const uint8_t *rgbe; uint32_t w, h; };
 struct DNoise { const uint8_t *rgba; uint32_t w, h, enabled; };
 
-struct Queue { float4 *o; float4 *d; float4 *T; };          // o.w = pixel slot bits, d.w = pdf of the sampling bounce (<0: camera)
+// o.w = pdf of the sampling bounce (<0: camera), d.w = pixel slot bits, T.w = x | y << 13 | sample << 26.
+// k_trace reads o and d; k_shade reads d and T (and o only for the emitter MIS weight / the G-buffer): the pdf rides
+// with the origin so that shading streams 48 B per ray (d, T, hit) instead of 64
+struct Queue { float4 *o; float4 *d; float4 *T; };
 struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w = pixel slot bits, c = contribution
 
 struct FrameCounters {
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
         }
         const uint32_t idx = DENSE ? vslot : block_compact(valid, &ctr->qcount[0], lds);
         if (valid) {
-            st_nt(q.o + idx, make_float4(p.origin.x, p.origin.y, p.origin.z, __uint_as_float(vslot)));
-            st_nt(q.d + idx, make_float4(d.x, d.y, d.z, -1.0f));
+            st_nt(q.o + idx, make_float4(p.origin.x, p.origin.y, p.origin.z, -1.0f));
+            st_nt(q.d + idx, make_float4(d.x, d.y, d.z, __uint_as_float(vslot)));
             q.T[idx] = make_float4(1.f, 1.f, 1.f, __uint_as_float(x | (y << 13) | (sample << 26)));  // pixel + sample ride along: no divisions in k_shade
         }
     }
@@ -787,16 +790,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
         bool want_next = false, want_shadow = false, is_surface = false;
         float4 no4, nd4, nT4, so4, sd4, sc4;
         if (i < count) {
-            const float4 o4 = ld_nt(qin.o + i), d4 = ld_nt(qin.d + i), T4 = ld_nt(qin.T + i), h4 = ld_nt(hits + i);
-            const uint32_t slot = __float_as_uint(o4.w);
+            const float4 d4 = ld_nt(qin.d + i), T4 = ld_nt(qin.T + i), h4 = ld_nt(hits + i);
+            const uint32_t slot = __float_as_uint(d4.w);
             const uint32_t pxy = __float_as_uint(T4.w);  // x | y << 13 | sample << 26 (k_raygen)
             const f3 d = mk3(d4.x, d4.y, d4.z);
             const f3 T = mk3(T4.x, T4.y, T4.z);
-            const float pdf_prev = d4.w;
             const uint32_t prim = __float_as_uint(h4.w);
             // primary-hit record for the G-buffer (SPEC §15.1); defaults cover miss / emitter / degenerate
             f3 g_n = neg(d), g_alb = mk3(1.0f, 1.0f, 1.0f);
-            f3 g_P = mk3(fmaf(d.x, h4.x, o4.x), fmaf(d.y, h4.x, o4.y), fmaf(d.z, h4.x, o4.z));
+            f3 g_P = mk3(0.f, 0.f, 0.f);
+            if (GBUF && bounce == 0) {
+                const float4 o4 = ld_nt(qin.o + i);
+                g_P = mk3(fmaf(d.x, h4.x, o4.x), fmaf(d.y, h4.x, o4.y), fmaf(d.z, h4.x, o4.z));
+            }
             if (prim == 0xFFFFFFFFu) {
                 const f3 e = env_lookup(probe, d);
                 float4 L = Lsum[slot];
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                 const float Le = lo4.w;
                 g_n = mk3(n4.x, n4.y, n4.z);
                 float w = 1.0f;
+                const float pdf_prev = ld_nt(qin.o + i).w;   // emitter hits are rare: the origin record is read only here
                 if (pdf_prev >= 0.0f) {
                     float cl = -dot(mk3(n4.x, n4.y, n4.z), d);
                     float area = 4.0f * (t4.w * b4.w);
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                                     if (contrib.x > 0.0f || contrib.y > 0.0f || contrib.z > 0.0f) {
                                         want_shadow = true;
                                         so4 = make_float4(Po.x, Po.y, Po.z, dist * 0.999f);
-                                        sd4 = make_float4(wi.x, wi.y, wi.z, o4.w);
+                                        sd4 = make_float4(wi.x, wi.y, wi.z, d4.w);
                                         sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
                                     }
                                 }
@@ -911,8 +918,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                             f3 Tn = mk3(T.x * wgt.x, T.y * wgt.y, T.z * wgt.z);
                             if (Tn.x > 0.0f || Tn.y > 0.0f || Tn.z > 0.0f) {
                                 want_next = true;
-                                no4 = make_float4(Po.x, Po.y, Po.z, o4.w);
-                                nd4 = make_float4(Ln.x, Ln.y, Ln.z, pdf);
+                                no4 = make_float4(Po.x, Po.y, Po.z, pdf);
+                                nd4 = make_float4(Ln.x, Ln.y, Ln.z, d4.w);
                                 nT4 = make_float4(Tn.x, Tn.y, Tn.z, T4.w);
                             }
                         }

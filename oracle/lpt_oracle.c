@@ -135,7 +135,7 @@ void orc_onb(const float n[3], float t[3], float b[3]) {
 }
 
 /* ------------------------------------------------------------------ scene */
-typedef struct { float lo[3], hi[3]; uint32_t left, right, first, count; } bnode; /* count>0: leaf */
+typedef struct { float lo[3], hi[3]; uint32_t left, right, first, count; uint32_t axis; } bnode; /* count>0: leaf; axis: split axis (near child first) */
 
 struct orc_scene {
     uint32_t n_tris;
@@ -148,7 +148,8 @@ struct orc_scene {
     uint32_t probe_w, probe_h; uint8_t *probe;
     uint32_t noise_w, noise_h; uint8_t *noise;
     float srgb_lut[256];
-    /* private acceleration structure: object-median BVH2 over triangle centroids */
+    /* private acceleration structure: binned-SAH BVH2 over triangle centroids (median split as the fall-back);
+       hits do not depend on it (SPEC §7), only the oracle's speed does */
     bnode *nodes; uint32_t n_nodes; uint32_t *order;
 };
 
@@ -206,18 +207,16 @@ static void tri_bounds(const orc_scene *s, uint32_t tri, float lo[3], float hi[3
     }
 }
 
-typedef struct { const float *cent; int axis; } sort_ctx;
-static _Thread_local sort_ctx g_sort;
-static int cmp_centroid(const void *a, const void *b) {
-    uint32_t ia = *(const uint32_t *)a, ib = *(const uint32_t *)b;
-    float ca = g_sort.cent[3 * ia + g_sort.axis], cb = g_sort.cent[3 * ib + g_sort.axis];
-    if (ca < cb) return -1;
-    if (ca > cb) return 1;
-    return ia < ib ? -1 : (ia > ib ? 1 : 0);
+static float half_area3(const float lo[3], const float hi[3]) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.0f) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
 }
 
+/* binned SAH (16 bins on the axis with the cheapest split); equal centroids fall back to an index median */
 static uint32_t build_rec(orc_scene *s, const float *cent, const float *tlo, const float *thi,
-                          uint32_t first, uint32_t count) {
+                          uint32_t first, uint32_t count, uint32_t depth) {
+    enum { NB = 16 };
     uint32_t id = s->n_nodes++;
     bnode *n = &s->nodes[id];
     float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
@@ -231,18 +230,63 @@ static uint32_t build_rec(orc_scene *s, const float *cent, const float *tlo, con
             if (cent[3 * t + a] > chi[a]) chi[a] = cent[3 * t + a];
         }
     }
-    n->first = first; n->count = 0; n->left = n->right = 0;
+    n->first = first; n->count = 0; n->left = n->right = 0; n->axis = 0;
     if (count <= 4) { n->count = count; return id; }
-    int axis = 0;
-    float ext = chi[0] - clo[0];
-    if (chi[1] - clo[1] > ext) { axis = 1; ext = chi[1] - clo[1]; }
-    if (chi[2] - clo[2] > ext) { axis = 2; ext = chi[2] - clo[2]; }
-    g_sort.cent = cent; g_sort.axis = axis;
-    qsort(s->order + first, count, sizeof(uint32_t), cmp_centroid);
-    uint32_t half = count / 2;
-    uint32_t l = build_rec(s, cent, tlo, thi, first, half);
-    uint32_t r = build_rec(s, cent, tlo, thi, first + half, count - half);
-    s->nodes[id].left = l; s->nodes[id].right = r;
+    int best_axis = -1; uint32_t best_bin = 0; float best_cost = 1e30f;
+    for (int a = 0; a < 3 && depth < 48u; ++a) {   /* beyond depth 48 only balanced splits: the traversal stack is finite */
+        const float ext = chi[a] - clo[a];
+        if (!(ext > 0.0f)) continue;
+        const float scale = (float)NB / ext;
+        uint32_t cnt[NB]; float blo[NB][3], bhi[NB][3];
+        for (int b = 0; b < NB; ++b) { cnt[b] = 0; for (int k = 0; k < 3; ++k) { blo[b][k] = 1e30f; bhi[b][k] = -1e30f; } }
+        for (uint32_t i = first; i < first + count; ++i) {
+            const uint32_t t = s->order[i];
+            int b = (int)((cent[3 * t + a] - clo[a]) * scale);
+            if (b < 0) b = 0;
+            if (b > NB - 1) b = NB - 1;
+            cnt[b]++;
+            for (int k = 0; k < 3; ++k) {
+                if (tlo[3 * t + k] < blo[b][k]) blo[b][k] = tlo[3 * t + k];
+                if (thi[3 * t + k] > bhi[b][k]) bhi[b][k] = thi[3 * t + k];
+            }
+        }
+        float rarea[NB]; uint32_t rcnt[NB];
+        float alo[3] = {1e30f, 1e30f, 1e30f}, ahi[3] = {-1e30f, -1e30f, -1e30f};
+        uint32_t acc = 0;
+        for (int b = NB - 1; b > 0; --b) {
+            for (int k = 0; k < 3; ++k) { if (blo[b][k] < alo[k]) alo[k] = blo[b][k]; if (bhi[b][k] > ahi[k]) ahi[k] = bhi[b][k]; }
+            acc += cnt[b];
+            rarea[b] = half_area3(alo, ahi); rcnt[b] = acc;
+        }
+        for (int k = 0; k < 3; ++k) { alo[k] = 1e30f; ahi[k] = -1e30f; }
+        acc = 0;
+        for (int b = 0; b < NB - 1; ++b) {
+            for (int k = 0; k < 3; ++k) { if (blo[b][k] < alo[k]) alo[k] = blo[b][k]; if (bhi[b][k] > ahi[k]) ahi[k] = bhi[b][k]; }
+            acc += cnt[b];
+            if (acc == 0 || rcnt[b + 1] == 0) continue;
+            const float cost = half_area3(alo, ahi) * (float)acc + rarea[b + 1] * (float)rcnt[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = (uint32_t)b; }
+        }
+    }
+    uint32_t half = 0;
+    if (best_axis >= 0) {
+        /* partition in place: bins <= best_bin to the left */
+        const float scale = (float)NB / (chi[best_axis] - clo[best_axis]);
+        uint32_t i = first, j = first + count;
+        while (i < j) {
+            const uint32_t t = s->order[i];
+            int b = (int)((cent[3 * t + best_axis] - clo[best_axis]) * scale);
+            if (b < 0) b = 0;
+            if (b > NB - 1) b = NB - 1;
+            if ((uint32_t)b <= best_bin) ++i;
+            else { --j; s->order[i] = s->order[j]; s->order[j] = t; }
+        }
+        half = i - first;
+    }
+    if (half == 0 || half == count) { half = count / 2; best_axis = 0; }   /* coincident centroids: split the run */
+    uint32_t l = build_rec(s, cent, tlo, thi, first, half, depth + 1u);
+    uint32_t r = build_rec(s, cent, tlo, thi, first + half, count - half, depth + 1u);
+    s->nodes[id].left = l; s->nodes[id].right = r; s->nodes[id].axis = (uint32_t)best_axis;
     return id;
 }
 
@@ -305,7 +349,7 @@ orc_scene *orc_scene_create(uint32_t n_tris, const orc_vertex *tri_verts, const 
             for (int a = 0; a < 3; ++a) cent[3 * (size_t)t + a] = 0.5f * (tlo[3 * (size_t)t + a] + thi[3 * (size_t)t + a]);
             s->order[t] = t;
         }
-        build_rec(s, cent, tlo, thi, 0, n_tris);
+        build_rec(s, cent, tlo, thi, 0, n_tris, 0u);
         free(cent); free(tlo); free(thi);
     }
     return s;
@@ -356,7 +400,7 @@ static void closest_one(const orc_scene *s, const float o[3], const float d[3], 
         for (uint32_t t = 0; t < s->n_tris; ++t) consider_tri(s, t, o, d, best, c);
     } else {
         float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-        uint32_t stack[128]; int sp = 0;
+        uint32_t stack[192]; int sp = 0;   /* depth <= 48 + log2(n) */
         stack[sp++] = 0;
         while (sp) {
             const bnode *n = &s->nodes[stack[--sp]];
@@ -364,9 +408,8 @@ static void closest_one(const orc_scene *s, const float o[3], const float d[3], 
             if (!box_hit(n, o, inv, best->t)) continue;
             if (n->count) {
                 for (uint32_t i = 0; i < n->count; ++i) consider_tri(s, s->order[n->first + i], o, d, best, c);
-            } else {
-                stack[sp++] = n->left; stack[sp++] = n->right;
-            }
+            } else if (d[n->axis] < 0.0f) { stack[sp++] = n->left; stack[sp++] = n->right; }   /* near child on top */
+            else { stack[sp++] = n->right; stack[sp++] = n->left; }
         }
     }
     /* SPEC §8: rectangular emitters, front face only, strictly closer than any triangle */
@@ -397,7 +440,7 @@ static int occluded_one(const orc_scene *s, const float o[3], const float d[3], 
         return 0;
     }
     float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
-    uint32_t stack[128]; int sp = 0;
+    uint32_t stack[192]; int sp = 0;   /* depth <= 48 + log2(n) */
     stack[sp++] = 0;
     while (sp) {
         const bnode *n = &s->nodes[stack[--sp]];
@@ -408,7 +451,8 @@ static int occluded_one(const orc_scene *s, const float o[3], const float d[3], 
                 if (c) c->tris++;
                 if (orc_ray_triangle(s->woop + 12 * (size_t)s->order[n->first + i], o, d, 0.0f, tmax, &t, &u, &v)) return 1;
             }
-        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+        } else if (d[n->axis] < 0.0f) { stack[sp++] = n->left; stack[sp++] = n->right; }
+        else { stack[sp++] = n->right; stack[sp++] = n->left; }
     }
     return 0;
 }
@@ -821,6 +865,32 @@ static void *worker(void *arg) {
     return NULL;
 }
 
+/* Persistent worker pool: threads are created once and parked on a condition variable between renders (a frame of
+   the bench workload is a few hundred milliseconds on a large host; creating 255 threads per frame is not free). */
+static struct {
+    pthread_mutex_t m; pthread_cond_t work, done;
+    pthread_t th[256]; uint64_t start_gen[256]; uint32_t n_threads;
+    job_t *job; uint64_t gen; uint32_t want, pending;
+    pthread_mutex_t render_lock;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, {0}, 0, NULL, 0, 0, 0, PTHREAD_MUTEX_INITIALIZER};
+
+static void *pool_main(void *arg) {
+    const uint32_t me = (uint32_t)(uintptr_t)arg;   /* 1-based: thread 0 is the caller */
+    pthread_mutex_lock(&g_pool.m);
+    uint64_t seen = g_pool.start_gen[me];           /* the generation before the render that created this thread */
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.work, &g_pool.m);
+        seen = g_pool.gen;
+        if (me >= g_pool.want) continue;            /* this render uses fewer threads */
+        job_t *j = g_pool.job;
+        pthread_mutex_unlock(&g_pool.m);
+        worker(j);
+        pthread_mutex_lock(&g_pool.m);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+    }
+    return NULL;
+}
+
 uint32_t orc_render(const orc_scene *s, const orc_render_params *p, float *accum, orc_counters *c) {
     job_t j;
     j.s = s; j.p = p; j.accum = accum; j.cam = make_camera(p); j.counters = c;
@@ -830,10 +900,23 @@ uint32_t orc_render(const orc_scene *s, const orc_render_params *p, float *accum
     if (j.x1 == 0u && j.y1 == 0u) { j.x0 = j.y0 = 0u; j.x1 = p->width; j.y1 = p->height; }
     uint32_t nt = p->threads ? p->threads : 1u;
     if (nt > 256u) nt = 256u;
-    pthread_t th[256];
-    for (uint32_t i = 1; i < nt; ++i) pthread_create(&th[i], NULL, worker, &j);
+    pthread_mutex_lock(&g_pool.render_lock);         /* one render at a time owns the pool */
+    pthread_mutex_lock(&g_pool.m);
+    while (g_pool.n_threads + 1u < nt) {             /* grow the pool to nt - 1 helpers */
+        const uint32_t idx = g_pool.n_threads + 1u;
+        g_pool.start_gen[idx] = g_pool.gen;
+        if (pthread_create(&g_pool.th[idx], NULL, pool_main, (void *)(uintptr_t)idx) != 0) { nt = idx; break; }
+        pthread_detach(g_pool.th[idx]);
+        g_pool.n_threads = idx;
+    }
+    g_pool.job = &j; g_pool.want = nt; g_pool.pending = nt - 1u; g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.work);
+    pthread_mutex_unlock(&g_pool.m);
     worker(&j);
-    for (uint32_t i = 1; i < nt; ++i) pthread_join(th[i], NULL);
+    pthread_mutex_lock(&g_pool.m);
+    while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.m);
+    pthread_mutex_unlock(&g_pool.m);
+    pthread_mutex_unlock(&g_pool.render_lock);
     pthread_mutex_destroy(&j.lock);
     return p->seed_counter + p->frames * p->max_bounces;
 }

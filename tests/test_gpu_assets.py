@@ -1,0 +1,130 @@
+"""-m gpu: the asset path the reference's default scene takes — several glTF files appended into ONE Scene
+(crates/standalone/src/lib.rs:107-123 loads DamagedHelmet and Sponza into the same scene, then moves the helmet) —
+with what those assets contain and the Cornell fixture does not: multi-primitive meshes with one material each,
+baseline-JPEG and PNG textures through `textures[i].source`, TRS nodes, strips / fans, u8 / u16 / u32 indices, a .glb
+and a .gltf with data URIs.  The real files are absent, so the two files are written here by the tiny
+glTF writer of tests/test_loader.py; the product loads, bakes and renders them and is compared bit for bit with the
+oracle, which reads the same bytes with its own loader (JPEG pixels are handed over from the product's decoder, SPEC §14.5)."""
+import io
+
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from loupiote_amd import testing as T
+from oracle import gltf_oracle as G, orc
+from test_loader import _jpeg, make_gltf, png_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(nx, nz, size, y, bump, seed):
+    """a displaced floor / wall patch: (positions, normals, uvs, indices)"""
+    rng = np.random.default_rng(seed)
+    xs, zs = np.meshgrid(np.linspace(-size, size, nx), np.linspace(-size, size, nz), indexing="xy")
+    h = y + bump * rng.standard_normal(xs.shape).astype(np.float32)
+    pos = np.stack([xs, h, zs], -1).reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (pos.shape[0], 1))
+    uv = np.stack([xs / (2 * size) + 0.5, zs / (2 * size) + 0.5], -1).reshape(-1, 2).astype(np.float32) * 3.0
+    idx = []
+    for j in range(nz - 1):
+        for i in range(nx - 1):
+            a = j * nx + i
+            idx += [a, a + nx, a + 1, a + 1, a + nx, a + nx + 1]
+    return pos, nrm, uv, np.array(idx)
+
+
+def _textures():
+    y, x = np.mgrid[0:64, 0:96]
+    albedo = np.stack([120 + 100 * np.sin(x / 7.0), 128 + 90 * np.cos(y / 5.0), 90 + x + y], -1).clip(0, 255).astype(np.uint8)
+    mra = np.stack([np.full_like(x, 255), 60 + 2 * x, (x // 12 + y // 12) % 2 * 255, np.full_like(x, 255)], -1).clip(0, 255).astype(np.uint8)
+    checker = np.kron(np.indices((8, 8)).sum(0) % 2, np.ones((8, 8))).astype(np.uint8)
+    marble = np.stack([200 * checker + 40, 180 * checker + 60, 160 * checker + 80], -1).astype(np.uint8)
+    return albedo, mra, marble
+
+
+def _files():
+    albedo, mra, marble = _textures()
+    p0, n0, uv0, i0 = _grid(9, 9, 4.0, 0.0, 0.03, 1)
+    p1, n1, uv1, i1 = _grid(5, 5, 1.0, 0.0, 0.0, 2)
+    quad = np.array([[-1, 0, 0], [1, 0, 0], [-1, 2, 0], [1, 2, 0]], np.float32)       # a strip
+    fan = np.array([[0, 0, 0], [1, 0, 0], [0.7, 0.7, 0], [0, 1, 0], [-0.7, 0.7, 0]], np.float32)
+    third = len(i0) // 3 // 3 * 3
+    meshes_a = [
+        # one mesh, three primitives with their own materials: the floor in three index ranges (u16 / u32 / u8-sized)
+        [dict(pos=p0, nrm=n0, uv=uv0, idx=i0[:third], material=0, idx_type="u16"),
+         dict(pos=p0, nrm=n0, uv=uv0, idx=i0[third:2 * third], material=1, idx_type="u32"),
+         dict(pos=p0, nrm=n0, uv=uv0, idx=i0[2 * third:], material=2)],
+        [dict(pos=quad, mode=5, material=1), dict(pos=fan, mode=6)],                      # strip + fan, the fan without material
+    ]
+    nodes_a = [{"mesh": 0}, {"mesh": 1, "translation": [0.0, 0.0, -3.0]},
+               {"mesh": 1, "translation": [2.5, 0.0, -1.0], "rotation": [0.0, 0.38268343, 0.0, 0.92387953], "scale": [0.8, 1.4, 0.8]}]
+    mats_a = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}, "roughnessFactor": 0.9}},
+              {"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.3, 0.2, 1.0], "metallicFactor": 0.0, "roughnessFactor": 0.4}},
+              {"pbrMetallicRoughness": {"baseColorTexture": {"index": 2}, "metallicFactor": 1.0, "roughnessFactor": 0.25}}]
+    file_a = make_gltf(meshes_a, nodes_a, mats_a, images=[_jpeg(albedo, quality=90, subsampling=2), png_bytes(mra), _jpeg(marble, quality=85, subsampling=0)],
+                       textures=[0, 1, 2], glb=True)
+    # second file (the "helmet"): its own image / material / mesh indices start at 0 again and must land after file A's
+    meshes_b = [[dict(pos=p1 * np.float32(0.8) + np.array([0, 1.0, 0], np.float32), nrm=n1, uv=uv1, idx=i1, material=0, idx_type="u8"),
+                 dict(pos=quad * np.float32(0.5), material=1, mode=5)]]
+    nodes_b = [{"mesh": 0, "translation": [-1.5, 0.2, 0.5]}, {"mesh": 0, "matrix": [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 1.5, 1.0, 1.0, 1]}]
+    mats_b = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicFactor": 0.0}},
+              {"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.5, 0.9, 1.0], "metallicFactor": 1.0, "roughnessFactor": 0.1}}]
+    file_b = make_gltf(meshes_b, nodes_b, mats_b, images=[_jpeg(marble[::-1].copy(), quality=80, subsampling=1)], textures=[0], glb=False)
+    return file_a, file_b
+
+
+def test_two_gltf_files_in_one_scene_render_like_the_oracle(device):
+    file_a, file_b = _files()
+    scene, osc = lp.Scene(), G.Scene()
+    for f in (file_a, file_b):                     # append semantics (gltf.rs:60,109-110)
+        lp.loaders.load_gltf(f, scene)
+        G.load_gltf(f, osc)
+    c = scene.counts()
+    assert (c.entries, c.materials, c.images) == (1 + 5 + 2, 1 + 3 + 2, 4)
+    assert c.instances == 1 + 3 + 2 * 2 + 2 * 2     # one instance per (node, primitive)
+    for name in ("materials", "entries", "vertices", "indices", "instances"):
+        assert getattr(scene, name).tobytes() == getattr(osc, name).tobytes(), name
+    m = scene.materials
+    assert list(m["albedo_texture"][1:]) == [0, 0xFFFFFFFF, 2, 3, 0xFFFFFFFF] and m["mra_texture"][1] == 1   # file B's texture 0 -> image 3
+    # JPEG pixels: the product's decoder is the source of truth for both sides (SPEC §14.5); PNG must agree exactly
+    assert np.array_equal(scene.image(1), osc.images[1])
+    for i in (0, 2, 3):
+        got = scene.image(i)
+        assert np.abs(got[..., :3].astype(int) - osc.images[i][..., :3].astype(int)).mean() < 5.0   # chroma-subsampled JPEG: replicated vs interpolated chroma (SPEC §14.5)
+        osc.images[i] = got
+    # move the "helmet" after load, as the reference's demo does (standalone/src/lib.rs:117-121)
+    idx = c.instances - 1
+    mv = scene.instances[idx]["model_to_world"].copy()
+    mv[12] += 0.4
+    scene.set_instance_transform(idx, mv)
+    osc.instances[idx]["model_to_world"] = mv
+    light = T.cornell_light()
+    light["origin"] = (0.0, 4.5, 0.0, 14.0)
+    scene.set_light(0, light)
+    osc.lights[0] = light[0]
+    probe = np.array([[[90, 110, 140, 128]]], np.uint8)
+    eye, direction = (0.5, 2.2, 6.5), (-0.05, -0.28, -1.0)
+    view = T.look(eye, direction)
+    W, H, B, F = 320, 200, 6, 3
+    for gpu_build in (False, True):
+        sg = lp.SceneGPU.new_from_scene(scene, device, gpu_build=gpu_build)
+        pr = lp.ProbeGPU(device, probe, 1, 1)
+        r = lp.Renderer(device, (W, H))
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (W, H))
+        r.set_max_bounces(B)
+        r.set_vfov(T.VFOV)
+        r.reset_accumulation()
+        r.accumulate = True
+        r.reset_ray_counts()
+        r.raytrace_n(view, F)
+        img, cnt = r.read_radiance(), r.ray_counts()
+        if not gpu_build:
+            o = orc.OracleScene.from_scene(osc, probe=probe)
+            acc, oc = o.render(W, H, view, T.VFOV, B, frames=F, want_counters=True)
+            ref = orc.resolve(acc)
+        assert (cnt.closest, cnt.shadow, cnt.shaded) == (oc.closest, oc.shadow, oc.shaded)
+        assert img.tobytes() == ref.tobytes()
+        assert float(img[..., :3].mean()) > 0.02 and cnt.shaded > W * H   # the textured geometry is in view
+        r.close(); pr.close(); sg.close()

@@ -27,7 +27,11 @@ def test_gpu_built_atrium_traces_like_the_host_built_one(device):
     gpu = lp.SceneGPU.new_from_scene(scene, device, gpu_build=True)
     hs, gs = host.stats(), gpu.stats()
     assert gs.triangles == hs.triangles == 262144 and 0 < gs.nodes < 262144 and 4 <= gs.max_depth <= 40
-    print("host: %d nodes depth %d %.1f ms | gpu: %d nodes depth %d %.1f ms" % (hs.nodes, hs.max_depth, hs.build_ms, gs.nodes, gs.max_depth, gs.build_ms))
+    print("host: %d nodes depth %d build %.1f ms upload %.1f ms | gpu: %d nodes depth %d build %.1f ms upload %.1f ms"
+          % (hs.nodes, hs.max_depth, hs.build_ms, hs.upload_ms, gs.nodes, gs.max_depth, gs.build_ms, gs.upload_ms))
+    # the GPU build never touches the host baker: instances are baked by k_bake_instance on the device
+    assert gs.host_baked_triangles == 0 and hs.host_baked_triangles == 262144
+    assert 0 < gs.upload_ms and gs.build_ms <= gs.upload_ms
     o, d = _rays(200000, (-12, 0.2, -6), (12, 9, 6), 3)
     a, b = host.trace_closest(o, d), gpu.trace_closest(o, d)
     assert a.tobytes() == b.tobytes() and (a["prim"] != 0xFFFFFFFF).mean() > 0.5
