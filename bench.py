@@ -265,6 +265,15 @@ def main():
     sc_ = r.ray_counts()
     s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest, sc_.shadow)
 
+    # N>1 (or --force-dist): rank 0's PRESENTED frame after an exchange must hold every pixel of the frame with its 4 samples
+    exchange_ok = None
+    if comm is not None:
+        frame(r)
+        fence()
+        if rank == 0:
+            img = r.read_radiance()
+            exchange_ok = bool(np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img)) and float(img[..., :3].mean()) > 0.0)
+
     latency = drop_in = None
     if extras:
         # ---- latency: one frame alone, host call to completion
@@ -319,7 +328,7 @@ def main():
                                    "(throughput; see latency_ms and drop_in for one frame alone / the unbatched protocol with read-back)"
                                    % (" + lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", FPS, P),
                        "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed,
-                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
+                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none", "exchange_frame_complete_on_rank0": exchange_ok,
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
             "ms_per_frame": elapsed / n_frames * 1e3,

@@ -433,6 +433,11 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
  * not change by a bit; only traversal coherence does.  flag: 1 = next-bounce queue only, 2 = shadow queue only, 3 (or any
  * other non-zero value) = both.  Default: off (measured slower on the bench scene). */
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
+/* The shard layout lpt_renderer_set_shard / lpt_renderer_exchange use, for hosts that run their own exchange (pure host
+ * arithmetic, no GPU needed): the number of pixel slots rank `rank` owns (whole tiles, including the part of edge tiles
+ * outside the image) and where its slots start in the concatenation of all ranks' slot arrays on rank 0. */
+int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world_size, uint32_t rank,
+                     uint32_t *out_slots, uint32_t *out_slot_offset);
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
 /* per-bounce queue sizes of the LAST traced frame: closest[b] = closest-hit rays of bounce b, shadow[b] = shadow rays
  * emitted by bounce b; up to `cap` entries each (either pointer may be NULL).  Blocking. */

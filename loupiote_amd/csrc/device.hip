@@ -1416,6 +1416,15 @@ int lpt_comm_info(const lpt_comm *c, int *rank, int *world) {
 int lpt_comm_group_begin(void) { RCCL_TRY(ncclGroupStart()); return LPT_OK; }
 int lpt_comm_group_end(void) { RCCL_TRY(ncclGroupEnd()); return LPT_OK; }
 
+int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, uint32_t *out_slots, uint32_t *out_offset) {
+    if (!world || rank >= world || !tile_w || !tile_h) return fail(LPT_ERR_INVALID_ARG, "lpt_shard_layout: bad shard (rank %u of %u, tile %ux%u)", rank, world, tile_w, tile_h);
+    const uint32_t n_tiles = div_up(width, tile_w) * div_up(height, tile_h), area = tile_w * tile_h;
+    const uint32_t a = shard_slot_offset(n_tiles, world, area, rank), b = shard_slot_offset(n_tiles, world, area, rank + 1u);
+    if (out_slots) *out_slots = b - a;
+    if (out_offset) *out_offset = a;
+    return LPT_OK;
+}
+
 int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: null");
     if (comm && comm->dev != r->dev) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: the communicator belongs to another device");

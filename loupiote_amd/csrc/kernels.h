@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             if (finished) {
                 if (shadow) {
                     if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
-                        const uint32_t slot = __float_as_uint(sq.d[ray].w);
+                        const uint32_t slot = __float_as_uint(rs.best.u);   // the pixel slot rides in the unused `u` of an any-hit ray
                         const float4 c = sq.c[ray];
                         float4 L = Lsum[slot];
                         L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
@@ -599,6 +599,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
                     float4 o4, d4;
                     if (use_s) { o4 = sq.o[idx]; d4 = sq.d[idx]; } else { o4 = q.o[idx]; d4 = q.d[idx]; }
                     ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), use_s ? o4.w : LPT_T_INF);
+                    if (use_s) rs.best.u = d4.w;   // kept for the deposit; a hit overwrites it, and then nothing is deposited
                     ray = idx;
                     shadow = use_s;
                     active = true;

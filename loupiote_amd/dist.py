@@ -35,6 +35,17 @@ def owned_slots(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
     return owned * tile_w * tile_h
 
 
+def shard_layout(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
+    """(slots, slot offset) of a rank as the library computes them (lpt_shard_layout): the staging layout of
+    lpt_renderer_exchange's owned-tile gather on rank 0"""
+    import ctypes as C
+    from . import _abi as A
+    n, off = C.c_uint32(), C.c_uint32()
+    if A.lib().lpt_shard_layout(width, height, tile_w, tile_h, world_size, rank, C.byref(n), C.byref(off)) != 0:
+        raise ValueError(A.lib().lpt_last_error().decode())
+    return n.value, off.value
+
+
 def reduce_radiance(buf, dst=0):
     """sum the (rgb-sum, sample-count) accumulation buffers of all ranks onto `dst`.
     Ownership is disjoint, so the sum is a gather; a reduce is the contract (north star)."""

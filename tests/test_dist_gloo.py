@@ -113,3 +113,80 @@ def test_owner_map_properties():
     om = D.owner_map(1920, 1080, 8)
     counts = np.bincount(om.reshape(-1), minlength=8)
     assert counts.max() - counts.min() <= D.TILE_W * D.TILE_H
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The native exchange (lpt_renderer_exchange, LPT_EXCHANGE_GATHER_TILES) on the CPU: its staging layout comes from the
+# library (lpt_shard_layout: pure host arithmetic, callable without a GPU); the slot <-> pixel rule is restated here
+# from kernels.h (slot_to_pixel / k_pack_owned / k_unpack_frame), the send / recv pairs become one gloo gather.
+def _slot_pixels(w, h, rank, world, tw, th):
+    """pixel index of every slot of `rank` (tile after owned tile, row-major inside a tile), -1 outside the image"""
+    tiles_x, tiles_y = (w + tw - 1) // tw, (h + th - 1) // th
+    out = []
+    for tile in range(rank, tiles_x * tiles_y, world):
+        ty, tx = divmod(tile, tiles_x)
+        ys, xs = np.mgrid[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+        px = np.where((xs < w) & (ys < h), ys * w + xs, -1)
+        out.append(px.reshape(-1))
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+def test_library_shard_layout_matches_the_ownership_rule():
+    sys.path.insert(0, ROOT)
+    from loupiote_amd import dist as D
+    for (w, h, n, tw, th) in [(1920, 1080, 8, 32, 8), (200, 120, 3, 32, 8), (33, 9, 2, 32, 8), (31, 7, 4, 8, 8), (97, 61, 5, 16, 8), (64, 16, 7, 32, 8)]:
+        off_expected = 0
+        for r in range(n):
+            slots, off = D.shard_layout(w, h, r, n, tw, th)
+            px = _slot_pixels(w, h, r, n, tw, th)
+            assert slots == px.size == D.owned_slots(w, h, r, n, tw, th) and off == off_expected
+            mask = np.zeros(w * h, bool)
+            mask[px[px >= 0]] = True
+            assert np.array_equal(mask.reshape(h, w), D.owned_mask(w, h, r, n, tw, th))
+            off_expected += slots
+    with pytest.raises(ValueError):
+        D.shard_layout(64, 64, 3, 3)
+
+
+def _worker_native_layout(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from loupiote_amd import dist as D
+    ok = True
+    for (W, H, tw, th) in [(100, 37, 32, 8), (203, 117, 8, 8), (33, 9, 16, 8)]:
+        rng = np.random.default_rng(7 * W + rank)
+        accum = rng.random((H * W, 4), dtype=np.float32)
+        accum[~D.owned_mask(W, H, rank, world, tw, th).reshape(-1)] = 0.0          # owned-pixels-only accumulation buffer
+        px = _slot_pixels(W, H, rank, world, tw, th)
+        packed = np.where((px >= 0)[:, None], accum[np.maximum(px, 0)], 0.0).astype(np.float32)      # k_pack_owned
+        layout = [D.shard_layout(W, H, q, world, tw, th) for q in range(world)]
+        pad = max(n for n, _ in layout)
+        send = torch.zeros((pad, 4))
+        send[: packed.shape[0]] = torch.from_numpy(packed)
+        recv = [torch.zeros((pad, 4)) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, recv, dst=0)                                                # ncclSend / grouped ncclRecv
+        ref = torch.from_numpy(accum.copy())
+        dist.reduce(ref, dst=0, op=dist.ReduceOp.SUM)                                 # LPT_EXCHANGE_REDUCE
+        if rank == 0:
+            staged = np.zeros((sum(n for n, _ in layout), 4), np.float32)
+            for q, (n, off) in enumerate(layout):
+                staged[off:off + n] = recv[q][:n].numpy()
+            frame = np.zeros((H * W, 4), np.float32)
+            for q in range(world):                                                   # k_unpack_frame
+                pq = _slot_pixels(W, H, q, world, tw, th)
+                sel = pq >= 0
+                frame[pq[sel]] = staged[layout[q][1] + np.flatnonzero(sel)]
+            ok = ok and frame.tobytes() == ref.numpy().tobytes() and bool((frame[:, 3] > 0).all())
+    if rank == 0:
+        open(out_path, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_gather_layout_equals_reduce(tmp_path, world):
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker_native_layout, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
