@@ -62,16 +62,35 @@ FRAMES_PER_STEP = 10
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def effective_cpus():
+    """host threads this process may actually run on: the cgroup CPU quota when there is one (the GPU boxes expose 256
+    hardware threads but grant 16 CPUs of time: oversubscribing them makes the oracle 40 % slower), else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(desc, view, threads):
     """The CPU oracle ("port") timed on the host cores on a bounded sample of the same workload:
-    whole 1920x1080 frames of 1 spp each (the same seeds the GPU step uses for its 1st, 2nd ... sample),
-    as many of the 4 as fit in ~15 s of wall time."""
+    whole 1920x1080 frames of 1 spp each (the same seeds the GPU frame uses for its 1st, 2nd ... sample),
+    as many as fit in ~12 s of wall time."""
     from oracle import orc  # checker only: the baseline leg, never the product path
     from oracle import harness
     s = harness.to_oracle(desc)
     sc = orc.OracleScene.from_scene(s, probe=desc["probe"])
     rays, secs, frames = 0, 0.0, 0
-    while frames < SPP and secs < 15.0:
+    while frames < 64 and secs < 12.0:   # whole 1-spp frames until ~12 s of wall time have been spent
         t0 = time.perf_counter()
         _, cnt = sc.render(WIDTH, HEIGHT, view, T.VFOV, DEPTH, frames=1, seed_counter=frames * DEPTH, threads=threads, want_counters=True)
         secs += time.perf_counter() - t0
@@ -82,10 +101,10 @@ def cpu_baseline(desc, view, threads):
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu": cpu,
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu": cpu, "cpu_quota": "threads = the cgroup CPU quota (cpu.max) when there is one",
             "per_thread": rays / secs / 1e6 / max(threads, 1),
-            "sample": "oracle/lpt_oracle.c (scalar C, persistent pthread pool, SAH BVH2, 16x16 tiles), %d of the %d spp of the same 1920x1080 depth-8 frame "
-                      "(%.1f Mrays in %.1f s); a reported baseline, not a target" % (frames, SPP, rays / 1e6, secs)}
+            "sample": "oracle/lpt_oracle.c (scalar C, persistent pthread pool, SAH BVH2, 16x16 tiles): %d whole 1-spp frames of the same 1920x1080 depth-8 "
+                      "workload with the seeds of the GPU frame's 1st, 2nd ... sample (%.1f Mrays in %.1f s); a reported baseline, not a target" % (frames, rays / 1e6, secs)}
 
 
 def load_profile_json(name):
@@ -357,7 +376,7 @@ def main():
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, view, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(desc, view, effective_cpus())
         elif world > 1:
             out["cpu_baseline"] = None
     else:

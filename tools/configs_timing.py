@@ -7,6 +7,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401,E402  (before libloupiote_hip.so: see INTEGRATION.md §7)
 
 import loupiote_amd as lp  # noqa: E402

@@ -77,11 +77,15 @@ def main(tag, out):
     if avg_ns:
         lim["solo_avg_launch_ms_rocprof"] = avg_ns / 1e6
         cycles = avg_ns * 1e-9 * CLOCK_HZ
+        g = per_launch(k, "GRBM_GUI_ACTIVE")   # summed over the 8 XCDs: busy cycles of the launch at the clock it actually ran at
         v = per_launch(k, "SQ_INSTS_VALU")
         if v:
             issue = v * (FAST_SHARE / FAST_RATE + (1 - FAST_SHARE) / SLOW_RATE)
-            lim["valu_issue"] = {"frac": issue / (SIMDS * cycles), "valu_wave_insts_per_launch": v, "fast_share": FAST_SHARE,
-                                 "rates_inst_per_clk_per_simd": [FAST_RATE, SLOW_RATE]}
+            lim["valu_issue"] = {"frac": issue / (SIMDS * (g / 8.0 if g else cycles)), "frac_at_nominal_clock": issue / (SIMDS * cycles),
+                                 "valu_wave_insts_per_launch": v, "insts_per_clk_per_simd": v / (SIMDS * (g / 8.0 if g else cycles)),
+                                 "busy_cycles_per_launch": (g / 8.0 if g else None), "fast_share": FAST_SHARE,
+                                 "rates_inst_per_clk_per_simd": [FAST_RATE, SLOW_RATE],
+                                 "ceiling_inst_per_clk_per_simd": 1.0 / (FAST_SHARE / FAST_RATE + (1 - FAST_SHARE) / SLOW_RATE)}
         r = bench.get("roofline", {})
         if r.get("bytes_per_launch"):
             gb = r["bytes_per_launch"] - r.get("rays_per_launch", 0) * 48.0   # nodes + triangles only
