@@ -36,6 +36,21 @@ class Device {  // device.rs:72-141
     lpt_device *h_ = nullptr;
 };
 
+// one rank of the multi-GPU frame exchange (new functionality; plain RCCL inside the library, include/lpt.h)
+class Comm {
+   public:
+    using Id = std::array<unsigned char, LPT_COMM_ID_BYTES>;
+    static Id unique_id() { Id id{}; check(lpt_comm_unique_id(id.data())); return id; }   // on ONE rank; ship the bytes to the others
+    Comm(const Device &dev, const Id &id, int rank, int world) { check(lpt_comm_create(dev.inner(), id.data(), rank, world, &h_)); }
+    ~Comm() { lpt_comm_destroy(h_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    lpt_comm *handle() const { return h_; }
+
+   private:
+    lpt_comm *h_ = nullptr;
+};
+
 class Scene {  // scene.rs:30-54
    public:
     Scene() { check(lpt_scene_create(&h_)); }
@@ -151,6 +166,9 @@ class Renderer {  // renderer.rs:169-811
     void set_seed(uint32_t s) { check(lpt_renderer_set_seed(h_, s)); }
     void set_vfov(float radians) { check(lpt_renderer_set_vfov(h_, radians)); }
     void set_shard(uint32_t rank, uint32_t world, uint32_t tile_w = 32, uint32_t tile_h = 8) { check(lpt_renderer_set_shard(h_, rank, world, tile_w, tile_h)); }
+    void set_comm(const Comm *comm) { check(lpt_renderer_set_comm(h_, comm ? comm->handle() : nullptr)); }     // = set_shard(rank, world, 32, 8) + the binding
+    void exchange(int mode = LPT_EXCHANGE_GATHER_TILES) { check(lpt_renderer_exchange(h_, mode)); }             // rank 0 presents the whole frame
+    void set_sort_queues(int flag) { check(lpt_renderer_set_sort_queues(h_, flag)); }
     lpt_ray_counts ray_counts() { lpt_ray_counts c; check(lpt_renderer_get_ray_counts(h_, &c)); return c; }
     /// multi-GPU denoising: this rank's filter inputs (device pointers) and, on rank 0 after the exchange, the filter passes
     void denoiser_inputs(void **noisy, void **gbuffer, void **motion, size_t *n_pixels) { check(lpt_renderer_denoiser_inputs(h_, noisy, gbuffer, motion, n_pixels)); }

@@ -399,6 +399,7 @@ int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **device_ptr, size_t 
 int lpt_comm_unique_id(void *out_id /* LPT_COMM_ID_BYTES */);
 /* ncclCommInitRank on `dev`.  Collective over the `world_size` callers; LPT_ERR_RCCL on failure. */
 int lpt_comm_create(lpt_device *dev, const void *id /* LPT_COMM_ID_BYTES */, int rank, int world_size, lpt_comm **out);
+/* Unbind every renderer first (lpt_renderer_set_comm(r, NULL) or destroy it). */
 int lpt_comm_destroy(lpt_comm *comm);
 int lpt_comm_info(const lpt_comm *comm, int *rank, int *world_size);
 /* ncclGroupStart / ncclGroupEnd: needed only when ONE thread drives several communicators (right column above). */
