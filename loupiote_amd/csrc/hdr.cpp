@@ -41,6 +41,9 @@ bool decode_hdr(const uint8_t *d, size_t n, uint32_t &width, uint32_t &height, s
     if (!read_line(d, n, off, line)) return false;
     int H = 0, W = 0;
     if (sscanf(line.c_str(), "-Y %d +X %d", &H, &W) != 2 || H <= 0 || W <= 0 || (size_t)W * (size_t)H > (1u << 28)) return false;
+    // untrusted header: a run-length code covers at most 127 pixels of one channel in two bytes, so the pixels cannot
+    // outnumber the remaining bytes by more than 127 / 8
+    if ((size_t)W * (size_t)H > 16u * (n - off) + 64u) return false;
     rgbe.assign((size_t)W * H * 4, 0);
     for (int y = 0; y < H; ++y) {
         uint8_t *row = &rgbe[(size_t)y * W * 4];

@@ -17,6 +17,8 @@ struct JHuff {
     uint8_t bits[17] = {0};
     uint8_t vals[256] = {0};
     int mincode[17], maxcode[18], valptr[17];
+    // a scan may name a table no DHT segment defined: such a table decodes nothing (every code length is "absent")
+    JHuff() { for (int l = 0; l < 17; ++l) { mincode[l] = 0; maxcode[l] = -1; valptr[l] = 0; } maxcode[17] = 0x7FFFFFFF; }
     void prepare() {
         int code = 0, k = 0;
         for (int l = 1; l <= 16; ++l) {
@@ -166,6 +168,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             }
             const int mcuw = 8 * hmax, mcuh = 8 * vmax;
             const int mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
+            // untrusted header: every coded 8x8 block takes at least two bits of the scan (a DC and an EOB code), so a
+            // frame with more blocks than that cannot be in this file
+            if ((size_t)mx * (size_t)my > 4u * (size - (off + len)) + 16u) return false;
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].bw = mx * comp[c].h * 8; comp[c].bh = my * comp[c].v * 8;
                 comp[c].plane.assign((size_t)comp[c].bw * comp[c].bh, 0);

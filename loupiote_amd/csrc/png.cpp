@@ -165,6 +165,8 @@ bool decode_png(const uint8_t *data, size_t size, Image &out) {
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch || (ctype == 3 && depth != 8)) return false;
     const size_t bpp = (size_t)ch * (depth / 8), stride = bpp * w;
+    // untrusted header: deflate expands by at most 1032:1, so an image larger than that cannot be in this file
+    if (w > (1u << 16) || h > (1u << 16) || (stride + 1) * (size_t)h > idat.size() * 1032u + 1024u) return false;
     std::vector<uint8_t> raw;
     raw.reserve((stride + 1) * h);
     if (!inflate(idat.data(), idat.size(), raw) || raw.size() < (stride + 1) * h) return false;
