@@ -420,11 +420,13 @@ int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm_or_null);
 /* Combines the ranks' accumulation buffers into rank 0's PRESENTED frame (a separate full-frame buffer: every rank's own
  * accumulation buffer stays owned-pixels-only, so progressive frames can be exchanged again and again).  Collective over
  * the communicator; asynchronous; a no-op without a communicator.  In the denoising BlitModes it exchanges the filter
- * inputs instead (lpt_renderer_denoiser_inputs) and runs lpt_renderer_denoise_filter on rank 0. */
+ * inputs instead (lpt_renderer_denoiser_inputs: noisy radiance, G-buffer, motion — owned pixels only, 40 B each, or three
+ * ncclReduce in LPT_EXCHANGE_REDUCE mode) and runs the temporal / a-trous / composite passes on rank 0. */
 int lpt_renderer_exchange(lpt_renderer *r, int mode);
 /* The same exchange among renderers of ONE process without RCCL (peer copies): `root` presents the frame assembled from
  * its own tiles and those of `peers` (n_peers renderers sharded with the same world size and tile shape, on the same or
- * on other devices of the process).  Used by single-process hosts and by the tests that emulate N ranks on one GPU. */
+ * on other devices of the process).  In the denoising BlitModes the filter inputs travel and `root` filters the frame.
+ * Used by single-process hosts and by the tests that emulate N ranks on one GPU. */
 int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers);
 
 /* new (north star: "a sorted shade / next-event stage using wavefront ballot / prefix-sum"; the reference dispatches the

@@ -1446,13 +1446,14 @@ static uint32_t slots_of_rank(const FrameParams &p, uint32_t q) {
     return shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q + 1u) - shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q);
 }
 // `frame` (rank 0) and the staging area for packed tiles: this rank's slots, or every rank's on the root
-static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_stage) {
+static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_stage, size_t bytes_per_slot = 16) {
     const size_t npx = (size_t)r->w * r->h;
     if (!r->frame) HIP_TRY(hipMalloc(&r->frame, sizeof(float4) * std::max<size_t>(npx, 1)));
     if (!r->xevent) HIP_TRY(hipEventCreateWithFlags(&r->xevent, hipEventDisableTiming));
     if (!want_stage) return LPT_OK;
     const FrameParams p = shard_params(r);
-    const size_t need = std::max<size_t>(root ? (size_t)p.n_tiles * p.tile_w * p.tile_h : (size_t)p.n_slots, 1);
+    const size_t slots = root ? (size_t)p.n_tiles * p.tile_w * p.tile_h : (size_t)p.n_slots;
+    const size_t need = std::max<size_t>((slots * bytes_per_slot + 15) / 16, 1);   // in float4 units
     if (r->xstage_elems < need) {
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->xstage) hipFree(r->xstage);
@@ -1485,9 +1486,33 @@ int lpt_renderer_exchange(lpt_renderer *r, int mode) {
         // denoising BlitModes: the per-pixel filter inputs are what is exchanged (zero outside a rank's tiles, so the sums
         // are gathers); rank 0 then filters the whole frame (SPEC §15.5)
         if (!r->den_temp || !r->den_inputs_ready) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: no denoising frame has been traced");
-        RCCL_TRY(ncclReduce(r->den_noisy, r->den_noisy, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
-        RCCL_TRY(ncclReduce(r->den_gbuf[r->den_cur], r->den_gbuf[r->den_cur], 4 * npx, ncclInt32, ncclSum, 0, c->comm, s));
-        RCCL_TRY(ncclReduce(r->den_motion, r->den_motion, 2 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+        if (mode == LPT_EXCHANGE_REDUCE) {
+            RCCL_TRY(ncclReduce(r->den_noisy, r->den_noisy, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+            RCCL_TRY(ncclReduce(r->den_gbuf[r->den_cur], r->den_gbuf[r->den_cur], 4 * npx, ncclInt32, ncclSum, 0, c->comm, s));
+            RCCL_TRY(ncclReduce(r->den_motion, r->den_motion, 2 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+        } else {
+            // owned tiles only: 40 B per owned pixel (41 MB per rank for a 3840x2160 frame on 8 GPUs, against 330 MB of reduces)
+            int st = ensure_exchange_buffers(r, root, true, 40);
+            if (st != LPT_OK) return st;
+            const FrameParams p = shard_params(r);
+            const uint32_t area = p.tile_w * p.tile_h;
+            unsigned char *stage = reinterpret_cast<unsigned char *>(r->xstage);
+            if (p.n_slots) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion, stage);
+            if (root) {
+                RCCL_TRY(ncclGroupStart());
+                for (uint32_t q = 1; q < p.world; ++q) {
+                    const uint32_t nq = slots_of_rank(p, q);
+                    if (!nq) continue;
+                    ncclResult_t e = ncclRecv(stage + 40u * (size_t)shard_slot_offset(p.n_tiles, p.world, area, q), 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
+                    if (e != ncclSuccess) { ncclGroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, ncclGetErrorString(e)); }
+                }
+                RCCL_TRY(ncclGroupEnd());
+                hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, stage, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
+            } else if (p.n_slots) {
+                RCCL_TRY(ncclSend(stage, 40u * (size_t)p.n_slots, ncclUint8, 0, c->comm, s));
+            }
+            HIP_TRY(hipGetLastError());
+        }
         if (root && r->world != 1u) { launch_filter(r, s); HIP_TRY(hipGetLastError()); }   // world == 1: raytrace() has filtered already
         r->den_inputs_ready = false;
         return LPT_OK;   // the composite has written the local target on rank 0
@@ -1524,39 +1549,58 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     if (!root || n_peers < 0 || (n_peers && !peers)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: null");
     if (root->rank != 0u || root->world != (uint32_t)n_peers + 1u)
         return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: root must be rank 0 of %d (is %u of %u)", n_peers + 1, root->rank, root->world);
-    if (root->mode != LPT_BLIT_PATHTRACE) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: path-traced frames only");
+    const bool den = root->mode != LPT_BLIT_PATHTRACE;   // denoising BlitModes: the filter inputs travel, rank 0 filters
     if (!root->w || !root->h || !root->accum) return LPT_OK;
     std::vector<char> seen(root->world, 0);
     seen[0] = 1;
     for (int i = 0; i < n_peers; ++i) {
         const lpt_renderer *q = peers[i];
-        if (!q || q->w != root->w || q->h != root->h || q->world != root->world || q->tile_w != root->tile_w || q->tile_h != root->tile_h || q->rank >= root->world || seen[q->rank])
+        if (!q || q->w != root->w || q->h != root->h || q->world != root->world || q->tile_w != root->tile_w || q->tile_h != root->tile_h || q->rank >= root->world || seen[q->rank] ||
+            (q->mode != LPT_BLIT_PATHTRACE) != den)
             return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: peer %d does not complete the shard set of the root", i);
+        if (den && (!q->den_temp || !q->den_inputs_ready)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: peer %d has not traced a denoising frame", i);
         seen[q->rank] = 1;
     }
+    if (den && (!root->den_temp || !root->den_inputs_ready)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: no denoising frame has been traced");
+    const size_t bps = den ? 40 : 16;
     HIP_TRY(hipSetDevice(root->dev->ordinal));
-    int st = ensure_exchange_buffers(root, true, true);
+    int st = ensure_exchange_buffers(root, true, true, bps);
     if (st != LPT_OK) return st;
     const FrameParams p0 = shard_params(root);
     const uint32_t area = p0.tile_w * p0.tile_h;
-    if (p0.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(root, p0.n_slots)), dim3(kBlock), 0, root->stream, p0, root->accum, root->xstage);
+    unsigned char *stage0 = reinterpret_cast<unsigned char *>(root->xstage);
+    if (p0.n_slots) {
+        if (den) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(root, p0.n_slots)), dim3(kBlock), 0, root->stream, p0, root->den_noisy, root->den_gbuf[root->den_cur], root->den_motion, stage0);
+        else hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(root, p0.n_slots)), dim3(kBlock), 0, root->stream, p0, root->accum, root->xstage);
+    }
     for (int i = 0; i < n_peers; ++i) {
         lpt_renderer *q = peers[i];
         HIP_TRY(hipSetDevice(q->dev->ordinal));
-        st = ensure_exchange_buffers(q, false, true);
+        st = ensure_exchange_buffers(q, false, true, bps);
         if (st != LPT_OK) return st;
         const FrameParams pq = shard_params(q);
         // the root's staging area may still be read by the unpack of its previous exchange
         if (root->xevent_recorded) HIP_TRY(hipStreamWaitEvent(q->stream, root->xevent, 0));
         if (pq.n_slots) {
-            hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->accum, q->xstage);
+            if (den) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->den_noisy, q->den_gbuf[q->den_cur], q->den_motion, reinterpret_cast<unsigned char *>(q->xstage));
+            else hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->accum, q->xstage);
             // the stand-in of ncclSend / ncclRecv inside one process: a (peer) copy into the root's staging area
-            HIP_TRY(hipMemcpyPeerAsync(root->xstage + shard_slot_offset(pq.n_tiles, pq.world, area, pq.rank), root->dev->ordinal, q->xstage, q->dev->ordinal,
-                                       sizeof(float4) * (size_t)pq.n_slots, q->stream));
+            HIP_TRY(hipMemcpyPeerAsync(stage0 + bps * (size_t)shard_slot_offset(pq.n_tiles, pq.world, area, pq.rank), root->dev->ordinal, q->xstage, q->dev->ordinal,
+                                       bps * (size_t)pq.n_slots, q->stream));
         }
+        if (den) q->den_inputs_ready = false;
         HIP_TRY(hipEventRecord(q->xevent, q->stream));
         HIP_TRY(hipSetDevice(root->dev->ordinal));
         HIP_TRY(hipStreamWaitEvent(root->stream, q->xevent, 0));
+    }
+    if (den) {
+        hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, stage0, root->den_noisy, root->den_gbuf[root->den_cur], root->den_motion);
+        launch_filter(root, root->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(root->xevent, root->stream));
+        root->xevent_recorded = true;
+        root->den_inputs_ready = false;
+        return LPT_OK;   // the composite has written the local target
     }
     hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, root->xstage, root->frame);
     HIP_TRY(hipGetLastError());

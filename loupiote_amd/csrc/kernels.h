@@ -1001,6 +1001,40 @@ __global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const fl
     }
 }
 
+// The same exchange for the denoising BlitModes: a rank's owned pixels of the three filter inputs (noisy radiance float4,
+// G-buffer uint4, motion float2 = 40 B per slot), staged as three consecutive runs of n_slots elements each.
+__global__ __launch_bounds__(kBlock) void k_pack_den(FrameParams p, const float4 *noisy, const uint4 *gbuf, const float2 *motion, unsigned char *out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    float4 *oa = reinterpret_cast<float4 *>(out);
+    uint4 *ob = reinterpret_cast<uint4 *>(out + 16u * (size_t)p.n_slots);
+    float2 *oc = reinterpret_cast<float2 *>(out + 32u * (size_t)p.n_slots);
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x, y;
+        const bool in = slot_to_pixel(p, slot, x, y);
+        const size_t px = in ? (size_t)y * p.width + x : 0;
+        oa[slot] = in ? noisy[px] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ob[slot] = in ? gbuf[px] : make_uint4(0u, 0u, 0u, 0u);
+        oc[slot] = in ? motion[px] : make_float2(0.f, 0.f);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_den(FrameParams p, const unsigned char *staged, float4 *noisy, uint4 *gbuf, float2 *motion) {
+    const uint32_t stride = gridDim.x * blockDim.x, npx = p.width * p.height;
+    const uint32_t area = p.tile_w * p.tile_h;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
+        const uint32_t y = i / p.width, x = i - y * p.width;
+        const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
+        const uint32_t tile = ty * p.tiles_x + tx;
+        const uint32_t owner = tile % p.world, k = tile / p.world;
+        const uint32_t slot = k * area + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        const uint32_t first = shard_slot_offset(p.n_tiles, p.world, area, owner);
+        const size_t n_owner = shard_slot_offset(p.n_tiles, p.world, area, owner + 1u) - first;
+        const unsigned char *base = staged + 40u * (size_t)first;
+        noisy[i] = reinterpret_cast<const float4 *>(base)[slot];
+        gbuf[i] = reinterpret_cast<const uint4 *>(base + 16u * n_owner)[slot];
+        motion[i] = reinterpret_cast<const float2 *>(base + 32u * n_owner)[slot];
+    }
+}
+
 // ------------------------------------------------------------------ denoiser passes (SPEC §15.2-15.4)
 // TemporalAccumulationPass (asvgf.rs:245-247): nearest reprojection + consistency test, moments, history
 // the frame's noisy radiance, per PIXEL (the path state is per slot of this rank's tiles): what the filter passes read,

@@ -73,6 +73,35 @@ def test_progressive_frames_exchanged_every_frame_equal_one_gpu(device, cornell_
     sg.close()
 
 
+@pytest.mark.parametrize("mode,world,tile", [(lp.BlitMode.DenoisedPathrace, 2, (32, 8)), (lp.BlitMode.Temporal, 3, (32, 8)), (lp.BlitMode.DenoisedPathrace, 5, (16, 8))])
+def test_denoising_modes_exchange_owned_tiles_of_the_filter_inputs(device, cornell_glb, mode, world, tile):
+    """config 5 on N GPUs: every rank traces its tiles, the owned pixels of the three filter inputs (40 B per pixel) travel
+    to rank 0, rank 0 filters the whole frame — bit-identical to the single-GPU denoiser frame after frame, with a moving
+    camera so that reprojection crosses tile borders (SPEC §15.5)"""
+    sg, pr = _setup(device, cornell_glb)
+    W, H = 203, 117
+    one = _renderer(device, sg, pr, W, H, 3)
+    ranks = [_renderer(device, sg, pr, W, H, 3, q, world, tile) for q in range(world)]
+    for r in [one] + ranks:
+        r.set_blit_mode(mode)
+        r.reset_accumulation()
+    for f in range(4):
+        view = T.look((0.15 * f, 0.6 + 0.05 * f, 13.5 - 0.2 * f), T.CORNELL_DIR)
+        one.raytrace(view)
+        for r in ranks:
+            r.raytrace(view)
+        ranks[0].exchange_local(ranks[1:])
+        assert ranks[0].read_radiance().tobytes() == one.read_radiance().tobytes(), "frame %d" % f
+        for got, want in zip(ranks[0].read_denoiser(), one.read_denoiser()):
+            assert got.tobytes() == want.tobytes()
+    with pytest.raises(lp.Error):
+        ranks[0].exchange_local(ranks[1:])           # the inputs of this frame have been consumed
+    for r in ranks + [one]:
+        r.close()
+    pr.close()
+    sg.close()
+
+
 def test_exchange_local_rejects_incomplete_shard_sets(device, cornell_glb):
     sg, pr = _setup(device, cornell_glb)
     a = _renderer(device, sg, pr, 64, 64, 2, 0, 3)

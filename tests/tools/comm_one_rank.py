@@ -53,11 +53,13 @@ def main():
     for r in (plain, shared):
         r.set_blit_mode(lp.BlitMode.DenoisedPathrace)
         r.reset_accumulation()
-    for frame in range(3):
+    for frame in range(4):
         plain.raytrace(view)
         shared.raytrace(view)
-        shared.exchange()
+        shared.exchange(lp.EXCHANGE_GATHER_TILES if frame % 2 == 0 else lp.EXCHANGE_REDUCE)
         assert shared.read_radiance().tobytes() == plain.read_radiance().tobytes(), frame
+        for got, want in zip(shared.read_denoiser(), plain.read_denoiser()):
+            assert got.tobytes() == want.tobytes()
     assert "torch" not in sys.modules
     shared.set_comm(None)
     for r in (plain, shared):
