@@ -46,3 +46,39 @@ def test_headless_driver_renders_and_saves(tmp_path):
     im = np.asarray(Image.open(out))
     assert im.shape == (240, 320, 4)          # downsample_factor 0.5 like the reference (renderer.rs:225)
     assert '"frames": 4' in p.stdout and im[..., 3].min() == 255
+
+
+def _build_c(tmp_path):
+    exe = str(tmp_path / "multi_gpu")
+    subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "multi_gpu.c"),
+                           "-L" + os.path.join(ROOT, "loupiote_amd"), "-lloupiote_hip", "-Wl,-rpath," + os.path.join(ROOT, "loupiote_amd"), "-lm", "-o", exe])
+    return exe
+
+
+def test_plain_c_multi_gpu_example_compiles_against_the_header(tmp_path):
+    """include/lpt.h is a C header: the example is C11, no C++ anywhere on the host side"""
+    assert os.path.exists(_build_c(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_multi_gpu_example_gives_the_same_frame_for_any_rank_count(tmp_path):
+    """examples/multi_gpu.c: N ranks inside one process (lpt_renderer_exchange_local), and ONE rank of a one-process RCCL job
+    (lpt_comm_unique_id through a file, lpt_comm_create, lpt_renderer_exchange) — the checksum of rank 0's presented frame does
+    not depend on N"""
+    import json
+    exe = _build_c(tmp_path)
+    glb = os.path.join(ROOT, "tests", "golden", "cornell-box.glb")
+    sums = []
+    for n in (1, 2, 3, 8):
+        p = subprocess.run([exe, glb, str(n), "203", "117", "3"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        j = json.loads(p.stdout.strip().splitlines()[-1])
+        assert j["covered"] == 203 * 117 and j["ranks"] == n
+        sums.append(j["checksum"])
+    env = dict(os.environ, LPT_RANK="0", LPT_WORLD="1", LPT_ID_FILE=str(tmp_path / "rccl.id"))
+    p = subprocess.run([exe, glb, "1", "203", "117", "3"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    assert j["multi_process"] == 1 and os.path.getsize(str(tmp_path / "rccl.id")) == 128
+    sums.append(j["checksum"])
+    assert len(set(sums)) == 1, sums
