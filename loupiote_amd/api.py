@@ -422,6 +422,10 @@ class Renderer:
         arr = (C.c_void_p * max(len(peers), 1))(*[p._h for p in peers])
         _check(A.lib().lpt_renderer_exchange_local(self._h, arr, len(peers)))
 
+    def set_lanes(self, lanes):
+        """wavefront lanes (1..4, default 2): consecutive raytrace() calls overlap on their own streams; bit-identical results"""
+        _check(A.lib().lpt_renderer_set_lanes(self._h, int(lanes)))
+
     def set_sort_queues(self, flag):
         """the shading pass emits both ray queues ordered by direction octant inside each block (bit-identical results)"""
         _check(A.lib().lpt_renderer_set_sort_queues(self._h, int(flag)))

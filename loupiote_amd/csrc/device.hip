@@ -71,10 +71,32 @@ struct lpt_probe {
 enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_COUNT };
 static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf"};
 
+// One independent wavefront context ("lane") of a renderer: everything a raytrace() call owns while its rays are in flight.
+// Consecutive raytrace() calls of ONE renderer take the lanes in turn (default 2), so the traversal / shading of call k+1
+// overlaps the drain tails of call k — what several renderers do for several frames, for the unchanged caller that issues
+// its samples one raytrace() at a time.  Accumulation stays on the renderer's stream, in call order (the fp32 sums are
+// order-sensitive), so results do not depend on the number of lanes.
+struct Wavefront {
+    hipStream_t stream = nullptr;   // the lane's own stream (unused with one lane: everything runs on the renderer's)
+    Queue q[2]{};
+    ShadowQueue sq{};
+    float4 *hits = nullptr, *Lsum = nullptr;
+    FrameCounters *ctr = nullptr;
+    uint32_t batch_cap = 0;         // samples per pixel the per-ray buffers can hold (raytrace_n); 0 = not allocated yet
+    hipEvent_t done = nullptr;      // recorded on `stream` behind the lane's last traversal / shading launch
+    hipEvent_t consumed = nullptr;  // recorded on the renderer's stream behind the accumulation that read this lane's Lsum
+    bool consumed_recorded = false;
+};
+constexpr int kMaxLanes = 4;
+
 struct lpt_renderer {
     lpt_device *dev = nullptr;
     hipStream_t stream = nullptr;   // every renderer enqueues on its OWN stream, so two renderers pipeline
                                     // consecutive frames (and a frame's collective overlaps the next frame)
+    Wavefront wf[kMaxLanes];
+    int n_lanes = 2;                // lpt_renderer_set_lanes / LPT_LANES
+    uint32_t lane_rr = 0;
+    int last_lane = 0;
     uint32_t req_w = 0, req_h = 0, w = 0, h = 0;
     float downsample = 0.5f;
     const lpt_scene_gpu *sg = nullptr;
@@ -97,12 +119,9 @@ struct lpt_renderer {
     uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
-    uint32_t batch_cap = 1;            // samples per pixel the per-ray buffers can hold (raytrace_n)
     uint32_t *n_slots_host = nullptr;  // pinned ring of dense ray counts (source of the async qcount[0] preset)
     uint32_t n_slots_ring = 0;
-    Queue q[2]{};
-    ShadowQueue sq{};
-    float4 *hits = nullptr, *Lsum = nullptr, *accum = nullptr, *scratch = nullptr;
+    float4 *accum = nullptr, *scratch = nullptr;
     // frame exchange (lpt_renderer_exchange): `frame` = the presented whole frame on rank 0 (accum stays owned-only),
     // `xstage` = packed owned tiles (this rank's; on rank 0 those of every rank, concatenated)
     lpt_comm *comm = nullptr;
@@ -111,7 +130,6 @@ struct lpt_renderer {
     bool presented = false;   // read_radiance / read_pixels / blit resolve from `frame` (set by an exchange, cleared by raytrace)
     hipEvent_t xevent = nullptr;
     bool xevent_recorded = false;
-    FrameCounters *ctr = nullptr;
     Totals *totals = nullptr;
     void *default_probe = nullptr;
     void *noise = nullptr;
@@ -762,15 +780,24 @@ static int ensure_denoiser(lpt_renderer *r) {
     HIP_TRY(hipMalloc(&r->den_noisy, sizeof(float4) * n));
     HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * n, s));
     HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * n, s));
+    HIP_TRY(hipStreamSynchronize(s));   // the primary pass of the first frame may run on a lane's stream
     return LPT_OK;
+}
+
+static void free_ray_buffers(Wavefront &wf) {
+    void *ptrs[] = {wf.q[0].o, wf.q[0].d, wf.q[0].T, wf.q[1].o, wf.q[1].d, wf.q[1].T, wf.sq.o, wf.sq.d, wf.sq.c, wf.hits, wf.Lsum};
+    for (void *p : ptrs) if (p) hipFree(p);
+    wf.q[0] = Queue{}; wf.q[1] = Queue{}; wf.sq = ShadowQueue{};
+    wf.hits = wf.Lsum = nullptr;
+    wf.batch_cap = 0;
 }
 
 static void free_frame_buffers(lpt_renderer *r) {
     free_denoiser(r);  // Renderer::resize re-creates the ASVGF resources (renderer.rs:347-355)
-    void *ptrs[] = {r->q[0].o, r->q[0].d, r->q[0].T, r->q[1].o, r->q[1].d, r->q[1].T, r->sq.o, r->sq.d, r->sq.c, r->hits, r->Lsum, r->accum, r->scratch};
-    for (void *p : ptrs) if (p) hipFree(p);
-    r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
-    r->hits = r->Lsum = r->accum = r->scratch = nullptr;
+    for (int l = 0; l < kMaxLanes; ++l) free_ray_buffers(r->wf[l]);
+    if (r->accum) hipFree(r->accum);
+    if (r->scratch) hipFree(r->scratch);
+    r->accum = r->scratch = nullptr;
     if (r->frame) hipFree(r->frame);
     if (r->xstage) hipFree(r->xstage);
     r->frame = r->xstage = nullptr;
@@ -788,24 +815,32 @@ static void shard_geometry(const lpt_renderer *r, uint32_t &tiles_x, uint32_t &n
     n_slots = owned * r->tile_w * r->tile_h;
 }
 
-// per-ray buffers (queues, hits, shadow queue, per-sample radiance): n_slots * batch_cap elements
-static int alloc_ray_buffers(lpt_renderer *r) {
-    void *ptrs[] = {r->q[0].o, r->q[0].d, r->q[0].T, r->q[1].o, r->q[1].d, r->q[1].T, r->sq.o, r->sq.d, r->sq.c, r->hits, r->Lsum};
-    for (void *p : ptrs) if (p) hipFree(p);
-    r->q[0] = Queue{}; r->q[1] = Queue{}; r->sq = ShadowQueue{};
-    r->hits = r->Lsum = nullptr;
-    const size_t n = std::max<size_t>((size_t)r->n_slots * r->batch_cap, 64);
-    if (n > 0x7FFFFFFFull) return fail(LPT_ERR_INVALID_ARG, "batch of %u samples x %u pixel slots exceeds 2^31 rays", r->batch_cap, r->n_slots);
+// per-ray buffers of one lane (queues, hits, shadow queue, per-sample radiance): n_slots * samples elements
+static int alloc_ray_buffers(lpt_renderer *r, Wavefront &wf, uint32_t samples) {
+    free_ray_buffers(wf);
+    const size_t n = std::max<size_t>((size_t)r->n_slots * samples, 64);
+    if (n > 0x7FFFFFFFull) return fail(LPT_ERR_INVALID_ARG, "batch of %u samples x %u pixel slots exceeds 2^31 rays", samples, r->n_slots);
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipMalloc(&r->q[k].o, sizeof(float4) * n));
-        HIP_TRY(hipMalloc(&r->q[k].d, sizeof(float4) * n));
-        HIP_TRY(hipMalloc(&r->q[k].T, sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&wf.q[k].o, sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&wf.q[k].d, sizeof(float4) * n));
+        HIP_TRY(hipMalloc(&wf.q[k].T, sizeof(float4) * n));
     }
-    HIP_TRY(hipMalloc(&r->sq.o, sizeof(float4) * n));
-    HIP_TRY(hipMalloc(&r->sq.d, sizeof(float4) * n));
-    HIP_TRY(hipMalloc(&r->sq.c, sizeof(float4) * n));
-    HIP_TRY(hipMalloc(&r->hits, sizeof(float4) * n));
-    HIP_TRY(hipMalloc(&r->Lsum, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.sq.o, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.sq.d, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.sq.c, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.hits, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.Lsum, sizeof(float4) * n));
+    wf.batch_cap = samples;
+    return LPT_OK;
+}
+
+// stream, events and counters of a lane (created on first use)
+static int ensure_lane(lpt_renderer *r, int l) {
+    Wavefront &wf = r->wf[l];
+    if (!wf.stream) HIP_TRY(hipStreamCreateWithFlags(&wf.stream, hipStreamNonBlocking));
+    if (!wf.done) HIP_TRY(hipEventCreateWithFlags(&wf.done, hipEventDisableTiming));
+    if (!wf.consumed) HIP_TRY(hipEventCreateWithFlags(&wf.consumed, hipEventDisableTiming));
+    if (!wf.ctr) HIP_TRY(hipMalloc(&wf.ctr, sizeof(FrameCounters)));
     return LPT_OK;
 }
 
@@ -817,9 +852,7 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     uint32_t tiles_x, n_tiles, n_slots;
     shard_geometry(r, tiles_x, n_tiles, n_slots);
     const size_t px = (size_t)r->w * r->h;
-    r->n_slots = n_slots;
-    int st = alloc_ray_buffers(r);
-    if (st != LPT_OK) return st;
+    r->n_slots = n_slots;   // the lanes' ray buffers are allocated by the first raytrace() that uses them
     HIP_TRY(hipMalloc(&r->accum, sizeof(float4) * px));
     HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
     HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->stream));
@@ -846,8 +879,8 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     // get_downsampled_size (renderer.rs:18-22)
     r->w = (uint32_t)((float)width * r->downsample);
     r->h = (uint32_t)((float)height * r->downsample);
-    hipError_t e = hipMalloc(&r->ctr, sizeof(FrameCounters));
-    if (e == hipSuccess) e = hipMalloc(&r->totals, sizeof(Totals));
+    if (const char *ev = getenv("LPT_LANES")) r->n_lanes = std::max(1, std::min(kMaxLanes, atoi(ev)));
+    hipError_t e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
     if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, 64 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
@@ -864,7 +897,13 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     hipSetDevice(r->dev->ordinal);
     hipStreamSynchronize(r->stream);
     free_frame_buffers(r);
-    if (r->ctr) hipFree(r->ctr);
+    for (int l = 0; l < kMaxLanes; ++l) {
+        Wavefront &wf = r->wf[l];
+        if (wf.stream) { hipStreamSynchronize(wf.stream); hipStreamDestroy(wf.stream); }
+        if (wf.done) hipEventDestroy(wf.done);
+        if (wf.consumed) hipEventDestroy(wf.consumed);
+        if (wf.ctr) hipFree(wf.ctr);
+    }
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->n_slots_host) hipHostFree(r->n_slots_host);
@@ -982,6 +1021,19 @@ int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode) {
     r->mode = mode;
     return LPT_OK;
 }
+int lpt_renderer_set_lanes(lpt_renderer *r, int lanes) {
+    if (!r || lanes < 1 || lanes > kMaxLanes) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_lanes: 1..%d", kMaxLanes);
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->stream));   // behind its waits: every lane's work
+    for (int l = 0; l < kMaxLanes; ++l) {
+        if (r->wf[l].stream) HIP_TRY(hipStreamSynchronize(r->wf[l].stream));
+        r->wf[l].consumed_recorded = false;
+        if (l >= lanes) free_ray_buffers(r->wf[l]);
+    }
+    r->n_lanes = lanes;
+    r->lane_rr = 0;
+    return LPT_OK;
+}
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_sort_queues: null");
     r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;   // 1: next-bounce queue, 2: shadow queue, 3 (or any other non-zero): both
@@ -1025,18 +1077,18 @@ static void harvest_slot(lpt_renderer *r, int slot) {
     r->ev_count[slot] = 0;
 }
 static inline int cur_slot(const lpt_renderer *r) { return (int)(r->ring_pos % lpt_renderer::kRing); }
-static inline void stage_begin(lpt_renderer *r, int stage) {
+static inline void stage_begin(lpt_renderer *r, int stage, hipStream_t stream) {
     if (!r->timings) return;
     const int slot = cur_slot(r);
     if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
     r->ev_stage[slot][r->ev_count[slot]] = stage;
-    hipEventRecord(r->ev_start[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->stream);
+    hipEventRecord(r->ev_start[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], stream);
 }
-static inline void stage_end(lpt_renderer *r) {
+static inline void stage_end(lpt_renderer *r, hipStream_t stream) {
     if (!r->timings) return;
     const int slot = cur_slot(r);
     if (r->ev_count[slot] >= lpt_renderer::kMaxEvents) return;
-    hipEventRecord(r->ev_stop[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], r->stream);
+    hipEventRecord(r->ev_stop[slot * lpt_renderer::kMaxEvents + r->ev_count[slot]], stream);
     r->ev_count[slot]++;
 }
 
@@ -1085,7 +1137,7 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
     if (!r->w || !r->h) return LPT_OK;
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    hipStream_t s = r->stream;
+    hipStream_t sm = r->stream;                  // accumulation, filter passes, bookkeeping, reads, the exchange: in call order
     r->presented = false;                        // a new sample: the exchanged frame (if any) is stale
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
 
@@ -1106,25 +1158,43 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     p.max_bounces = nb;
     p.n_samples = n_samples;
     p.fc_inc0 = r->accumulate ? 1u : 0u;
-    if (n_samples > r->batch_cap && p.n_slots) {
-        HIP_TRY(hipStreamSynchronize(s));
-        r->batch_cap = n_samples;
-        int st = alloc_ray_buffers(r);
-        if (st != LPT_OK) return st;
-    }
     const uint32_t n_rays = p.n_slots * n_samples;
     const bool denoise = r->mode != LPT_BLIT_PATHTRACE;
+    // the lane (Wavefront) this call's rays live in: consecutive calls take the lanes in turn; the denoising modes
+    // carry frame-to-frame state (G-buffer ping-pong, motion) and stay on lane 0
+    const bool split = r->n_lanes > 1;           // the wavefront runs on the lane's own stream
+    const int lane = (denoise || !split) ? 0 : (int)(r->lane_rr++ % (uint32_t)r->n_lanes);
+    {
+        int st = ensure_lane(r, lane);
+        if (st != LPT_OK) return st;
+    }
+    Wavefront &wf = r->wf[lane];
+    hipStream_t s = split ? wf.stream : sm;
+    r->last_lane = lane;
+    if (n_samples > wf.batch_cap && p.n_slots) {
+        HIP_TRY(hipStreamSynchronize(sm));       // everything that read this lane's buffers has been enqueued behind `sm`'s waits
+        HIP_TRY(hipStreamSynchronize(s));
+        int st = alloc_ray_buffers(r, wf, n_samples);
+        if (st != LPT_OK) return st;
+    }
     GBufArgs gb{};
     if (denoise) {
         int st = ensure_denoiser(r);
         if (st != LPT_OK) return st;
+    }
+    // the accumulation that consumed this lane's previous radiance.  A denoising frame also overwrites what the previous
+    // frame's filter passes read (G-buffer ping-pong, motion) — and on a sharded frame those are enqueued by a later call
+    // (lpt_renderer_exchange / denoise_filter) — so it waits for everything the renderer's stream holds so far.
+    if (split && denoise) { HIP_TRY(hipEventRecord(wf.consumed, sm)); wf.consumed_recorded = true; }
+    if (split && wf.consumed_recorded) HIP_TRY(hipStreamWaitEvent(s, wf.consumed, 0));
+    if (denoise) {
         r->den_cur = 1 - r->den_cur;         // asvgf.start() (renderer.rs:467)
         if (r->world != 1u) {
             // sharded frame: this rank fills only its tiles; the rest must read as zero for the exchange
             const size_t npx = (size_t)r->w * r->h;
             HIP_TRY(hipMemsetAsync(r->den_gbuf[r->den_cur], 0, sizeof(uint4) * npx, s));
             HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * npx, s));
-            HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * npx, s));
+            HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * npx, sm));
         }
         gb.gbuf = r->den_gbuf[r->den_cur];
         gb.motion = r->den_motion;
@@ -1138,7 +1208,7 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     if (r->timings) { r->ring_pos++; harvest_slot(r, cur_slot(r)); }
 
     if (p.n_slots) {
-        HIP_TRY(hipMemsetAsync(r->ctr, 0, sizeof(FrameCounters), s));
+        HIP_TRY(hipMemsetAsync(wf.ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
@@ -1151,69 +1221,78 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         const size_t lds = stack_bytes(sc);
 
         // "ray generation" (:444-448)
-        stage_begin(r, ST_RAYGEN);
+        stage_begin(r, ST_RAYGEN, s);
         const bool dense = (r->w % r->tile_w == 0u) && (r->h % r->tile_h == 0u);
         if (dense) {
             uint32_t *src = r->n_slots_host + (r->n_slots_ring++ & 63u);  // pinned; stays valid until the copy has run
             *src = n_rays;
-            HIP_TRY(hipMemcpyAsync(&r->ctr->qcount[0], src, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_raygen<true>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+            HIP_TRY(hipMemcpyAsync(&wf.ctr->qcount[0], src, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_raygen<true>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, wf.q[0], wf.Lsum, wf.ctr);
         } else {
-            hipLaunchKernelGGL(k_raygen<false>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, r->q[0], r->Lsum, r->ctr);
+            hipLaunchKernelGGL(k_raygen<false>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, wf.q[0], wf.Lsum, wf.ctr);
         }
-        stage_end(r);
+        stage_end(r, s);
 
         uint32_t seed = r->seed;
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
         // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
         // instead of 2*nb; split (LPT_MERGE_TRACE=0): IntersectorPass and the shadow pass as separate launches.
         auto trace = [&](int cb, int sb) {
-            stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW);  // :457-464, :493-498
-            const Queue qin = r->q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
-            if (r->stats) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->sq, r->Lsum, r->ctr, cb, sb, r->refill);
-            else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->sq, r->Lsum, r->ctr, cb, sb, r->refill);
-            stage_end(r);
+            stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
+            const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
+            if (r->stats) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+            stage_end(r, s);
         };
         if (r->merge_trace) trace(0, -1);
         for (uint32_t b = 0; b < nb; ++b) {
             seed += 1u;                          // :453, :487
-            const Queue qin = r->q[b & 1u], qout = r->q[(b + 1u) & 1u];
+            const Queue qin = wf.q[b & 1u], qout = wf.q[(b + 1u) & 1u];
             if (!r->merge_trace) {
-                stage_begin(r, ST_INTERSECT);    // :457-464, :493-498
-                if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
-                else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, r->hits, r->ctr, (int)b, r->refill);
-                stage_end(r);
+                stage_begin(r, ST_INTERSECT, s);    // :457-464, :493-498
+                if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.ctr, (int)b, r->refill);
+                else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.ctr, (int)b, r->refill);
+                stage_end(r, s);
             }
-            stage_begin(r, ST_SHADE);            // :471-480, :502-508
+            stage_begin(r, ST_SHADE, s);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
-                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb, r->sort_queues);
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, r->hits, qout, r->sq, r->Lsum, r->ctr, (int)b, seed, gb, r->sort_queues);
-            stage_end(r);
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+            stage_end(r, s);
             if (r->merge_trace) {
                 trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);
             } else {
-                stage_begin(r, ST_SHADOW);
-                if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, r->sq, r->Lsum, r->ctr, (int)b, r->refill);
-                stage_end(r);
+                stage_begin(r, ST_SHADOW, s);
+                if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, wf.sq, wf.Lsum, wf.ctr, (int)b, r->refill);
+                else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, wf.sq, wf.Lsum, wf.ctr, (int)b, r->refill);
+                stage_end(r, s);
             }
+        }
+        // the wavefront is done; what follows reads its radiance on the renderer's stream, behind every earlier call's
+        if (split) {
+            HIP_TRY(hipEventRecord(wf.done, s));
+            HIP_TRY(hipStreamWaitEvent(sm, wf.done, 0));
         }
         if (r->mode == LPT_BLIT_PATHTRACE) {
             // AccumulationPass (:523-538)
-            stage_begin(r, ST_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->accum);
-            stage_end(r);
+            stage_begin(r, ST_ACCUM, sm);
+            hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, sm, p, wf.Lsum, r->accum);
+            stage_end(r, sm);
         } else {
             // per-pixel filter inputs; on a sharded frame (world > 1) the caller now exchanges noisy / gbuffer / motion
             // (lpt_renderer_denoiser_inputs) and rank 0 calls lpt_renderer_denoise_filter
-            stage_begin(r, ST_ASVGF);
-            hipLaunchKernelGGL(k_den_scatter, dim3(stream_blocks), dim3(kBlock), 0, s, p, r->Lsum, r->den_noisy);
+            stage_begin(r, ST_ASVGF, sm);
+            hipLaunchKernelGGL(k_den_scatter, dim3(stream_blocks), dim3(kBlock), 0, sm, p, wf.Lsum, r->den_noisy);
             r->den_inputs_ready = true;
-            if (r->world == 1u) launch_filter(r, s);
-            stage_end(r);
+            if (r->world == 1u) launch_filter(r, sm);
+            stage_end(r, sm);
         }  // GBuffer / MotionVector: the primary pass has written the debug targets; nothing else runs (:539)
-        hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, s, r->ctr, r->totals, nb);
+        hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, sm, wf.ctr, r->totals, nb);
+        if (split) {
+            HIP_TRY(hipEventRecord(wf.consumed, sm));
+            wf.consumed_recorded = true;
+        }
         HIP_TRY(hipGetLastError());
     }
     // bookkeeping of n emulated calls: { raytrace(); accumulate = true (app.rs:318); } x n
@@ -1368,8 +1447,10 @@ int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     const uint32_t n = std::min<uint32_t>(cap, (uint32_t)kMaxBounces);
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (closest && n) HIP_TRY(hipMemcpy(closest, r->ctr->qcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-    if (shadow && n) HIP_TRY(hipMemcpy(shadow, r->ctr->shcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    const FrameCounters *ctr = r->wf[r->last_lane].ctr;
+    if (!ctr) { if (closest) memset(closest, 0, sizeof(uint32_t) * n); if (shadow) memset(shadow, 0, sizeof(uint32_t) * n); return LPT_OK; }
+    if (closest && n) HIP_TRY(hipMemcpy(closest, ctr->qcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    if (shadow && n) HIP_TRY(hipMemcpy(shadow, ctr->shcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
     return LPT_OK;
 }
 

@@ -59,3 +59,51 @@ def test_sorted_queues_atrium_textured(device):
     assert a[1:] == s[1:]
     pr.close()
     sg.close()
+
+
+@pytest.mark.parametrize("mode", [lp.BlitMode.Pahtrace, lp.BlitMode.DenoisedPathrace])
+def test_wavefront_lanes_do_not_change_a_bit(device, cornell_glb, mode):
+    """lpt_renderer_set_lanes: consecutive raytrace() calls overlap on 1 / 2 / 3 / 4 lanes (own streams, own ray queues);
+    accumulation stays in call order, so every intermediate and final frame is bit-identical — also when reads, batched
+    calls and a resize are interleaved"""
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+
+    def run(lanes):
+        r = lp.Renderer(device, (203, 117))
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (203, 117))
+        r.set_max_bounces(5)
+        r.set_vfov(T.VFOV)
+        r.set_lanes(lanes)
+        r.set_blit_mode(mode)
+        r.reset_accumulation()
+        r.accumulate = True
+        r.reset_ray_counts()
+        outs = []
+        for k in range(7):
+            r.raytrace(view)
+            if k in (2, 5):
+                outs.append(r.read_radiance())
+        r.raytrace_n(view, 3)
+        outs.append(r.read_radiance())
+        r.resize(device, sg, pr, (96, 64))
+        r.set_max_bounces(5)
+        for _ in range(5):
+            r.raytrace(view)
+        outs.append(r.read_radiance())
+        c = r.ray_counts()
+        outs.append(np.array([c.closest, c.shadow, c.shaded]))
+        r.close()
+        return outs
+
+    base = run(1)
+    for lanes in (2, 3, 4):
+        for a, b in zip(base, run(lanes)):
+            assert a.tobytes() == b.tobytes(), lanes
+    pr.close()
+    sg.close()
