@@ -321,6 +321,11 @@ extern "C" {
 // ============================================================================ Device
 int lpt_device_create(int hip_ordinal, lpt_device **out) {
     if (!out) return fail(LPT_ERR_INVALID_ARG, "lpt_device_create: null out");
+    // A renderer spreads its work over several HIP streams (wavefront lanes, several renderers in flight); the ROCm runtime
+    // maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, of which these streams get two) and streams that share a
+    // queue serialise.  Ask for 8 unless the host chose a value; it only takes effect if the HIP runtime has not been
+    // initialised by someone else yet.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
