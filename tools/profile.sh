@@ -4,7 +4,8 @@
 #   trace : rocprofv3 --kernel-trace --stats of the bench command (three frames in flight)
 #   solo  : the same with --pipeline 1 (one frame at a time): what roofline.frac is computed from
 #   pmc*  : counter passes, collected on their own (never combined with --sys-trace etc.)
-# The program after `--` is python3 itself (no env/bash hop).  --no-extras keeps the latency / drop-in legs (launches of
+# The program after `--` is python3 itself (no env/bash hop); every pass is bounded by `timeout` (a counter set the hardware
+# cannot collect makes rocprofv3 abort and then hang in its finaliser).  --no-extras keeps the latency / drop-in legs (launches of
 # other sizes) out of the per-kernel averages.
 set -u
 TAG=${1:-r02}
@@ -13,13 +14,13 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o t -- python3 $ARGS --pipeline 1 > $OUT/solo.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solo -o t -- python3 $ARGS --pipeline 1 > $OUT/solo.log 2>&1
 PARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --frames-per-step 3"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o p -- python3 $PARGS > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc2 -o p -- python3 $PARGS > $OUT/pmc2.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc3 -o p -- python3 $PARGS > $OUT/pmc3.log 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc4 -o p -- python3 $PARGS > $OUT/pmc4.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o p -- python3 $PARGS > $OUT/pmc1.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc2 -o p -- python3 $PARGS > $OUT/pmc2.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc3 -o p -- python3 $PARGS > $OUT/pmc3.log 2>&1
+timeout 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc4 -o p -- python3 $PARGS > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | xargs ls -la
 for f in $OUT/*.log; do echo "== $f"; grep -E '"value"|rror' $f | cut -c1-200 | head -3; done
 # reduce: summaries that get committed under profiles/
