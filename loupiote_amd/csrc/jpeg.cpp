@@ -1,8 +1,9 @@
-// jpeg.cpp — dependency-free baseline JPEG decoder for glTF images (DamagedHelmet / Sponza carry JPEG
+// jpeg.cpp — dependency-free JPEG decoder for glTF images (DamagedHelmet / Sponza carry JPEG
 // textures; the reference decodes them through the `gltf` crate's `image` import,
-// crates/lib/src/loaders/gltf.rs:12-44,150-153).  Sequential DCT, Huffman, 8-bit, 1 or 3 components,
-// sampling factors up to 2x2, restart intervals.  Progressive / arithmetic / 12-bit streams are rejected
-// (the loader then reports Error::FileNotFound like any other undecodable image).
+// crates/lib/src/loaders/gltf.rs:12-44,150-153).  Sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection and
+// successive approximation, coefficients kept for the whole frame and transformed after the last scan) DCT, Huffman, 8-bit,
+// 1 or 3 components, sampling factors up to 2x2, restart intervals.  Arithmetic-coded / lossless / 12-bit streams are
+// rejected (the loader then reports Error::FileNotFound like any other undecodable image).
 // Output: RGBA8 with alpha 0 for the missing channel, exactly like the RGB -> RGBA expansion of gltf.rs:26-38.
 // Chroma is upsampled by replication and the IDCT is a separable float transform, so pixels can differ
 // from libjpeg's (fancy upsampling, integer IDCT) by a few code values; tests bound the difference.
@@ -33,7 +34,14 @@ struct JHuff {
     }
 };
 
-struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
+struct Comp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+    int bw = 0, bh = 0;              // plane size in pixels (whole MCUs)
+    std::vector<uint8_t> plane;
+    // progressive only: the quantised coefficients of every block (natural order), refined scan by scan
+    std::vector<int16_t> coef;
+    int nbx = 0, nby = 0;            // blocks a non-interleaved scan of this component covers
+};
 
 struct Reader {
     const uint8_t *p, *end;
@@ -97,6 +105,99 @@ void idct8x8(const float *in, uint8_t *out, int stride) {
 
 uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
 
+// ---- progressive mode (SOF2; ITU T.81 annex G): one block of one scan.  `c` = the block's 64 coefficients (natural order).
+struct ProgScan { int ss, se, ah, al; int eobrun; };
+
+bool prog_dc(Reader &r, const JHuff &h, Comp &cp, int16_t *c, const ProgScan &sc) {
+    if (sc.ah == 0) {
+        const int t = decode_sym(r, h);
+        if (t > 11) return false;
+        cp.pred += t ? extend(r.bits(t), t) : 0;
+        c[0] = (int16_t)(cp.pred * (1 << sc.al));
+    } else if (r.bit()) {
+        c[0] = (int16_t)(c[0] | (1 << sc.al));
+    }
+    return r.ok;
+}
+
+bool prog_ac(Reader &r, const JHuff &h, int16_t *c, ProgScan &sc) {
+    if (sc.ah == 0) {                                   // first pass over this band
+        if (sc.eobrun) { --sc.eobrun; return true; }
+        for (int k = sc.ss; k <= sc.se;) {
+            const int rs = decode_sym(r, h), run = rs >> 4, sz = rs & 15;
+            if (!r.ok) return false;
+            if (sz == 0) {
+                if (run < 15) { sc.eobrun = (1 << run) - 1; if (run) sc.eobrun += r.bits(run); break; }
+                k += 16;
+            } else {
+                k += run;
+                if (k > sc.se) return false;
+                c[kZig[k]] = (int16_t)(extend(r.bits(sz), sz) * (1 << sc.al));
+                ++k;
+            }
+        }
+        return r.ok;
+    }
+    // refinement: one more bit for every coefficient that is already non-zero, new +-1 coefficients in between
+    const int p1 = 1 << sc.al, m1 = -(1 << sc.al);
+    int k = sc.ss;
+    auto refine = [&](int16_t &v) {
+        if (r.bit() && (v & p1) == 0) v = (int16_t)(v + (v >= 0 ? p1 : m1));
+    };
+    if (sc.eobrun == 0) {
+        bool eob = false;
+        while (k <= sc.se) {
+            const int rs = decode_sym(r, h);
+            if (!r.ok) return false;
+            int run = rs >> 4;
+            const int sz = rs & 15;
+            int val = 0;
+            if (sz == 0) {
+                if (run < 15) { sc.eobrun = (1 << run) - 1; if (run) sc.eobrun += r.bits(run); eob = true; break; }   // end of band: the rest below
+            } else {
+                if (sz != 1) return false;
+                val = r.bit() ? p1 : m1;
+            }
+            while (k <= sc.se) {
+                int16_t &v = c[kZig[k]];
+                ++k;
+                if (v != 0) { refine(v); continue; }
+                if (run == 0) { if (sz) v = (int16_t)val; break; }   // run == 0 with sz == 0 only happens for ZRL's 16th zero
+                --run;
+            }
+        }
+        if (!eob) return r.ok;
+        // an EOB (run) starts in this block: its remaining non-zero coefficients are still refined
+        for (; k <= sc.se; ++k) { int16_t &v = c[kZig[k]]; if (v != 0) refine(v); }
+        return r.ok;   // eobrun counts the FOLLOWING blocks
+    }
+    for (; k <= sc.se; ++k) { int16_t &v = c[kZig[k]]; if (v != 0) refine(v); }
+    --sc.eobrun;
+    return r.ok;
+}
+
+// planes (one byte per sample, whole MCUs) -> RGBA8: replicated chroma, BT.601 full-range YCbCr (SPEC §14.5)
+void planes_to_rgba(const Comp *comp, int ncomp, int W, int H, int hmax, int vmax, Image &out) {
+    out.width = (uint32_t)W; out.height = (uint32_t)H;
+    out.rgba8.assign((size_t)W * H * 4, 0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            uint8_t *dst = &out.rgba8[((size_t)y * W + x) * 4];
+            const float Y = comp[0].plane[(size_t)(y * comp[0].v / vmax) * comp[0].bw + (x * comp[0].h / hmax)];
+            if (ncomp == 1) { dst[0] = (uint8_t)Y; continue; }  // grey: one channel, the rest stay 0 (gltf.rs:26-38)
+            const float cb = comp[1].plane[(size_t)(y * comp[1].v / vmax) * comp[1].bw + (x * comp[1].h / hmax)] - 128.f;
+            const float cr = comp[2].plane[(size_t)(y * comp[2].v / vmax) * comp[2].bw + (x * comp[2].h / hmax)] - 128.f;
+            const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
+            for (int k = 0; k < 3; ++k) { const int q = (int)std::floor(rgb[k] + 0.5f); dst[k] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
+        }
+}
+
+void skip_to_after_rst(Reader &r) {
+    r.reset();  // skip to past the RSTn marker
+    while (r.p + 1 < r.end && !(r.p[0] == 0xFF && r.p[1] >= 0xD0 && r.p[1] <= 0xD7)) ++r.p;
+    if (r.p + 1 < r.end) r.p += 2;
+}
+
 }  // namespace
 
 bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
@@ -106,12 +207,32 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
     Comp comp[3];
     int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0;
     size_t off = 2;
-    bool have_frame = false;
+    bool have_frame = false, progressive = false, have_scan = false;
+    int mx = 0, my = 0;   // MCUs per row / column
+    int n_scans = 0;
+    // progressive: all scans have been read (EOI, or the data ended): dequantise, inverse transform, convert
+    auto finish_progressive = [&]() -> bool {
+        if (!progressive || !have_scan) return false;
+        for (int c = 0; c < ncomp; ++c) {
+            Comp &cp = comp[c];
+            cp.plane.assign((size_t)cp.bw * cp.bh, 0);
+            const int bpr = cp.bw / 8;
+            for (int by = 0; by < cp.bh / 8; ++by)
+                for (int bx = 0; bx < bpr; ++bx) {
+                    const int16_t *cf = &cp.coef[((size_t)by * bpr + bx) * 64];
+                    float blk[64];
+                    for (int k = 0; k < 64; ++k) blk[k] = (float)cf[k] * (float)qt[cp.tq][k];
+                    idct8x8(blk, &cp.plane[(size_t)by * 8 * cp.bw + (size_t)bx * 8], cp.bw);
+                }
+        }
+        planes_to_rgba(comp, ncomp, W, H, hmax, vmax, out);
+        return true;
+    };
     while (off + 4 <= size) {
         if (data[off] != 0xFF) { ++off; continue; }
         const uint8_t m = data[off + 1];
         off += 2;
-        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0xFF) { if (m == 0xFF) --off; continue; }
+        if (m == 0xD8 || m == 0x01 || m == 0x00 || (m >= 0xD0 && m <= 0xD7) || m == 0xFF) { if (m == 0xFF) --off; continue; }   // 0x00: a stuffed byte of entropy data
         if (m == 0xD9) break;
         if (off + 2 > size) return false;
         const size_t len = be16(data + off);
@@ -141,8 +262,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
                 i += (size_t)total;
                 h.prepare();
             }
-        } else if (m == 0xC0 || m == 0xC1) {  // baseline / extended sequential, Huffman
-            if (n < 6 || seg[0] != 8) return false;
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {  // baseline / extended sequential / progressive, Huffman
+            if (have_frame || n < 6 || seg[0] != 8) return false;
+            progressive = m == 0xC2;
             H = be16(seg + 1); W = be16(seg + 3); ncomp = seg[5];
             if ((ncomp != 1 && ncomp != 3) || !W || !H || n < 6u + 3u * (size_t)ncomp) return false;
             for (int c = 0; c < ncomp; ++c) {
@@ -151,11 +273,81 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
                 hmax = std::max(hmax, comp[c].h); vmax = std::max(vmax, comp[c].v);
             }
             have_frame = true;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            return false;  // progressive, lossless, arithmetic: not supported
+            mx = (W + 8 * hmax - 1) / (8 * hmax); my = (H + 8 * vmax - 1) / (8 * vmax);
+            if (progressive) {
+                // untrusted header: the first DC scan spends at least one bit on every block of the frame
+                if ((size_t)mx * (size_t)my > 8u * size + 16u) return false;
+                for (int c = 0; c < ncomp; ++c) {
+                    Comp &cp = comp[c];
+                    cp.bw = mx * cp.h * 8; cp.bh = my * cp.v * 8;
+                    cp.coef.assign((size_t)(cp.bw / 8) * (cp.bh / 8) * 64, 0);
+                    cp.nbx = ((W * cp.h + hmax - 1) / hmax + 7) / 8;
+                    cp.nby = ((H * cp.v + vmax - 1) / vmax + 7) / 8;
+                }
+            }
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return false;  // lossless, hierarchical, arithmetic: not supported
         } else if (m == 0xDD) {
             if (n < 2) return false;
             restart = be16(seg);
+        } else if (m == 0xDA && progressive) {  // SOS of a progressive image: one of several scans
+            if (!have_frame || n < 1 || ++n_scans > 256) return false;   // real files carry ~10 scans; each one costs a pass over the frame
+            const int ns = seg[0];
+            if (ns < 1 || ns > ncomp || n < 1u + 2u * (size_t)ns + 3u) return false;
+            int which[3] = {0, 0, 0};
+            for (int k = 0; k < ns; ++k) {
+                const int id = seg[1 + 2 * k];
+                int c = -1;
+                for (int j = 0; j < ncomp; ++j) if (comp[j].id == id) c = j;
+                if (c < 0) return false;
+                for (int j = 0; j < k; ++j) if (which[j] == c) return false;
+                which[k] = c;
+                comp[c].td = seg[2 + 2 * k] >> 4; comp[c].ta = seg[2 + 2 * k] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3) return false;
+            }
+            ProgScan sc{seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15, 0};
+            if (sc.ss > 63 || sc.se > 63 || sc.ss > sc.se || sc.al > 13 || sc.ah > 13) return false;
+            if ((sc.ss == 0) != (sc.se == 0)) return false;          // a scan is either DC only or AC only
+            if (sc.ss > 0 && ns != 1) return false;                  // AC scans carry one component
+            Reader r{data + off + len, data + size};
+            for (int k = 0; k < ns; ++k) comp[which[k]].pred = 0;
+            int count = 0;
+            auto restart_here = [&]() {
+                if (restart && count && count % restart == 0) {
+                    skip_to_after_rst(r);
+                    for (int k = 0; k < ns; ++k) comp[which[k]].pred = 0;
+                    sc.eobrun = 0;
+                }
+                ++count;
+            };
+            if (ns == 1) {   // non-interleaved: the component's own blocks, row by row
+                Comp &cp = comp[which[0]];
+                const int bpr = cp.bw / 8;
+                for (int by = 0; by < cp.nby; ++by)
+                    for (int bx = 0; bx < cp.nbx; ++bx) {
+                        restart_here();
+                        int16_t *cf = &cp.coef[((size_t)by * bpr + bx) * 64];
+                        const bool ok = sc.ss == 0 ? prog_dc(r, hdc[cp.td], cp, cf, sc) : prog_ac(r, hac[cp.ta], cf, sc);
+                        if (!ok) return false;
+                    }
+            } else {         // interleaved (DC scans): MCU by MCU
+                for (int my_ = 0; my_ < my; ++my_)
+                    for (int mx_ = 0; mx_ < mx; ++mx_) {
+                        restart_here();
+                        for (int k = 0; k < ns; ++k) {
+                            Comp &cp = comp[which[k]];
+                            const int bpr = cp.bw / 8;
+                            for (int by = 0; by < cp.v; ++by)
+                                for (int bx = 0; bx < cp.h; ++bx) {
+                                    int16_t *cf = &cp.coef[((size_t)(my_ * cp.v + by) * bpr + (mx_ * cp.h + bx)) * 64];
+                                    if (!prog_dc(r, hdc[cp.td], cp, cf, sc)) return false;
+                                }
+                        }
+                    }
+            }
+            have_scan = true;
+            off = (size_t)(r.p - data);   // the marker loop resumes behind the entropy-coded data of this scan
+            continue;
         } else if (m == 0xDA) {  // SOS: the one scan of a sequential image
             if (!have_frame || n < 1 || seg[0] != ncomp || n < 1u + 2u * (size_t)ncomp + 3u) return false;
             for (int k = 0; k < ncomp; ++k) {
@@ -166,8 +358,6 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
                 comp[c].td = seg[2 + 2 * k] >> 4; comp[c].ta = seg[2 + 2 * k] & 15;
                 if (comp[c].td > 3 || comp[c].ta > 3) return false;
             }
-            const int mcuw = 8 * hmax, mcuh = 8 * vmax;
-            const int mx = (W + mcuw - 1) / mcuw, my = (H + mcuh - 1) / mcuh;
             // untrusted header: every coded 8x8 block takes at least two bits of the scan (a DC and an EOB code), so a
             // frame with more blocks than that cannot be in this file
             if ((size_t)mx * (size_t)my > 4u * (size - (off + len)) + 16u) return false;
@@ -181,9 +371,7 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             for (int my_ = 0; my_ < my; ++my_)
                 for (int mx_ = 0; mx_ < mx; ++mx_) {
                     if (restart && count && count % restart == 0) {
-                        r.reset();  // skip to past the RSTn marker
-                        while (r.p + 1 < r.end && !(r.p[0] == 0xFF && r.p[1] >= 0xD0 && r.p[1] <= 0xD7)) ++r.p;
-                        if (r.p + 1 < r.end) r.p += 2;
+                        skip_to_after_rst(r);
                         for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
                     }
                     ++count;
@@ -209,23 +397,12 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
                                 idct8x8(blk, &comp[c].plane[(size_t)py * comp[c].bw + px], comp[c].bw);
                             }
                 }
-            out.width = (uint32_t)W; out.height = (uint32_t)H;
-            out.rgba8.assign((size_t)W * H * 4, 0);
-            for (int y = 0; y < H; ++y)
-                for (int x = 0; x < W; ++x) {
-                    uint8_t *dst = &out.rgba8[((size_t)y * W + x) * 4];
-                    const float Y = comp[0].plane[(size_t)(y * comp[0].v / vmax) * comp[0].bw + (x * comp[0].h / hmax)];
-                    if (ncomp == 1) { dst[0] = (uint8_t)Y; continue; }  // grey: one channel, the rest stay 0 (gltf.rs:26-38)
-                    const float cb = comp[1].plane[(size_t)(y * comp[1].v / vmax) * comp[1].bw + (x * comp[1].h / hmax)] - 128.f;
-                    const float cr = comp[2].plane[(size_t)(y * comp[2].v / vmax) * comp[2].bw + (x * comp[2].h / hmax)] - 128.f;
-                    const float rgb[3] = {Y + 1.402f * cr, Y - 0.344136f * cb - 0.714136f * cr, Y + 1.772f * cb};
-                    for (int k = 0; k < 3; ++k) { const int q = (int)std::floor(rgb[k] + 0.5f); dst[k] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
-                }
+            planes_to_rgba(comp, ncomp, W, H, hmax, vmax, out);
             return true;
         }
         off += len;
     }
-    return false;
+    return finish_progressive();   // EOI (or the end of the data) after the scans of a progressive image
 }
 
 }  // namespace lpt

@@ -262,6 +262,10 @@ def _jpeg(arr, **kw):
     (dict(quality=92, subsampling=2), 3.0, 24),                         # 4:2:0
     (dict(quality=60, subsampling=0, restart_marker_blocks=5), 0.2, 4), # DRI / RSTn
     (dict(quality=85, subsampling=2, restart_marker_rows=1), 3.0, 24),
+    (dict(quality=92, subsampling=0, progressive=True), 0.1, 4),        # SOF2: spectral selection + successive approximation
+    (dict(quality=75, subsampling=2, progressive=True), 3.0, 24),
+    (dict(quality=50, subsampling=1, progressive=True, optimize=True), 2.5, 16),
+    (dict(quality=85, subsampling=2, progressive=True, restart_marker_rows=1), 3.0, 24),
 ])
 def test_jpeg_decoder_close_to_pil(kw, mean_tol, max_tol):
     """Baseline JPEG textures (DamagedHelmet / Sponza): the product decoder against libjpeg (PIL) — float IDCT
@@ -286,7 +290,12 @@ def test_jpeg_grey_and_unsupported_modes():
     got = s.image(0)
     ref = np.asarray(Image.open(io.BytesIO(raw))).astype(int)
     assert np.abs(got[..., 0].astype(int) - ref).max() <= 2 and np.all(got[..., 1:] == 0)   # R8 -> (r,0,0,0)
-    for broken in (_jpeg(_smooth_rgb(), progressive=True), raw[: len(raw) // 2], raw[:20]):
+    prog = _jpeg(grey, quality=90, progressive=True)      # progressive grey: decodes like the baseline file of the same image
+    s2 = lp.Scene()
+    lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[prog], textures=[0]), s2)
+    ref2 = np.asarray(Image.open(io.BytesIO(prog))).astype(int)
+    assert np.abs(s2.image(0)[..., 0].astype(int) - ref2).max() <= 2
+    for broken in (raw[: len(raw) // 2], raw[:20], prog[:40]):
         with pytest.raises(lp.Error) as e:
             lp.loaders.load_gltf(make_gltf([[{"pos": QUAD}]], [{"mesh": 0}], images=[broken], textures=[0]), lp.Scene())
         assert e.value.kind == "FileNotFound"

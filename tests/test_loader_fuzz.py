@@ -42,6 +42,7 @@ def test_mutated_files_never_trip_the_sanitizers(fuzzer, cornell_glb):
         "u.gltf": make_gltf([[dict(pos=QUAD, mode=5)]], [{"mesh": 0}], images=[png_bytes(img)], textures=[0]),
         "s.png": png_bytes(img), "g.png": png_bytes(img[..., 0]), "a.png": png_bytes(np.dstack([img, img[..., :1]])),
         "s.jpg": _jpeg(img, quality=90, subsampling=2), "t.jpg": _jpeg(img, quality=70, subsampling=0, restart_marker_blocks=5), "u.jpg": _jpeg(img[..., 0], quality=80),
+        "p.jpg": _jpeg(img, quality=85, subsampling=2, progressive=True), "q.jpg": _jpeg(img[..., 0], quality=60, progressive=True, restart_marker_rows=1),
         "r.hdr": _hdr_bytes(px, rle=True), "f.hdr": _hdr_bytes(px, rle=False),
     }
     paths = []
