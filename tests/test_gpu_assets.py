@@ -1,7 +1,7 @@
 """-m gpu: the asset path the reference's default scene takes — several glTF files appended into ONE Scene
 (crates/standalone/src/lib.rs:107-123 loads DamagedHelmet and Sponza into the same scene, then moves the helmet) —
 with what those assets contain and the Cornell fixture does not: multi-primitive meshes with one material each,
-baseline-JPEG and PNG textures through `textures[i].source`, TRS nodes, strips / fans, u8 / u16 / u32 indices, a .glb
+baseline- and progressive-JPEG and PNG textures through `textures[i].source`, TRS nodes, strips / fans, u8 / u16 / u32 indices, a .glb
 and a .gltf with data URIs.  The real files are absent, so the two files are written here by the tiny
 glTF writer of tests/test_loader.py; the product loads, bakes and renders them and is compared bit for bit with the
 oracle, which reads the same bytes with its own loader (JPEG pixels are handed over from the product's decoder, SPEC §14.5)."""
@@ -70,7 +70,7 @@ def _files():
     nodes_b = [{"mesh": 0, "translation": [-1.5, 0.2, 0.5]}, {"mesh": 0, "matrix": [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 1.5, 1.0, 1.0, 1]}]
     mats_b = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicFactor": 0.0}},
               {"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.5, 0.9, 1.0], "metallicFactor": 1.0, "roughnessFactor": 0.1}}]
-    file_b = make_gltf(meshes_b, nodes_b, mats_b, images=[_jpeg(marble[::-1].copy(), quality=80, subsampling=1)], textures=[0], glb=False)
+    file_b = make_gltf(meshes_b, nodes_b, mats_b, images=[_jpeg(marble[::-1].copy(), quality=80, subsampling=1, progressive=True)], textures=[0], glb=False)
     return file_a, file_b
 
 
