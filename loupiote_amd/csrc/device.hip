@@ -132,6 +132,7 @@ struct lpt_renderer {
     bool xevent_recorded = false;
     Totals *totals = nullptr;
     void *default_probe = nullptr;
+    float *srgb_thr = nullptr;   // 256 floats: the linear value at which sRGB code i starts (k_tonemap, SPEC §13.2)
     void *noise = nullptr;
     uint32_t noise_w = 0, noise_h = 0;
     // denoiser path (reference render/asvgf.rs ScreenResources :9-152): 2x ping-pong {radiance, gbuffer, moments,
@@ -890,6 +891,16 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, 64 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
     if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
+    if (e == hipSuccess) e = hipMalloc(&r->srgb_thr, 256 * sizeof(float));
+    if (e == hipSuccess) {
+        float thr[256];
+        thr[0] = 0.0f;
+        for (int i = 1; i < 256; ++i) {   // inverse OETF at (i - 0.5) / 255 in binary64, rounded once
+            const double v = ((double)i - 0.5) / 255.0;
+            thr[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+        }
+        e = hipMemcpy(r->srgb_thr, thr, sizeof thr, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e)); }
     int st = alloc_frame_buffers(r);
     if (st != LPT_OK) { lpt_renderer_destroy(r); return st; }
@@ -911,6 +922,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     }
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
+    if (r->srgb_thr) hipFree(r->srgb_thr);
     if (r->n_slots_host) hipHostFree(r->n_slots_host);
     if (r->xevent) hipEventDestroy(r->xevent);
     if (r->stream) hipStreamDestroy(r->stream);
@@ -1353,7 +1365,7 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
             hipLaunchKernelGGL(k_debug_view, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, r->den_gbuf[r->den_cur], r->den_motion,
                                (uchar4 *)r->scratch, (int)r->w, (int)r->h, r->mode);
         else
-            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, presented_target(r), (uchar4 *)r->scratch, n);
+            hipLaunchKernelGGL(k_tonemap, dim3(div_up(n, kBlock)), dim3(kBlock), 0, r->stream, presented_target(r), (uchar4 *)r->scratch, n, r->srgb_thr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->stream);

@@ -1168,17 +1168,25 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4 *accum, float4 
     const float4 a = accum[i];
     mean[i] = a.w > 0.0f ? make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-__device__ __forceinline__ uint8_t encode_srgb8(float c) {
+// SPEC §13.2: code i starts at thr[i] (the inverse OETF of (i - 0.5) / 255, computed in binary64 on the host): an 8-step search
+// on float comparisons — exact, and independent of the device's powf
+__device__ __forceinline__ uint8_t encode_srgb8(float c, const float *thr) {
     c = clampf(c, 0.0f, 1.0f);
-    float s = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 0.41666666f) - 0.055f;
-    return (uint8_t)(s * 255.0f + 0.5f);
+    uint32_t idx = 0;
+#pragma unroll
+    for (uint32_t step = 128u; step; step >>= 1)
+        if (idx + step <= 255u && c >= thr[idx + step]) idx += step;
+    return (uint8_t)idx;
 }
-__global__ __launch_bounds__(kBlock) void k_tonemap(const float4 *accum, uchar4 *out, uint32_t n) {
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float4 *accum, uchar4 *out, uint32_t n, const float *thr_global) {
+    __shared__ float thr[256];
+    thr[threadIdx.x] = thr_global[threadIdx.x];  // kBlock == 256
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 a = accum[i];
     const bool ok = a.w > 0.0f;
-    out[i] = make_uchar4(encode_srgb8(ok ? a.x / a.w : 0.f), encode_srgb8(ok ? a.y / a.w : 0.f), encode_srgb8(ok ? a.z / a.w : 0.f), 255);
+    out[i] = make_uchar4(encode_srgb8(ok ? a.x / a.w : 0.f, thr), encode_srgb8(ok ? a.y / a.w : 0.f, thr), encode_srgb8(ok ? a.z / a.w : 0.f, thr), 255);
 }
 
 // stand-alone ray queries (lpt_trace_closest / lpt_trace_occluded)

@@ -932,10 +932,25 @@ void orc_resolve(const float *accum, uint32_t n, float *mean) {
         } else { mean[4 * (size_t)i + 0] = mean[4 * (size_t)i + 1] = mean[4 * (size_t)i + 2] = mean[4 * (size_t)i + 3] = 0.0f; }
     }
 }
+/* SPEC §13.2: the sRGB OETF rounded to 8 bits, evaluated EXACTLY: code i is produced from the linear value where the ideal
+   curve crosses (i - 0.5) / 255 — the inverse OETF in binary64, rounded to binary32 once — so the result is a table search on
+   float comparisons and does not depend on anybody's powf. */
+static float g_srgb_thr[256];
+static int g_srgb_thr_ready = 0;
+void orc_srgb_thresholds(float out[256]) {
+    out[0] = 0.0f;
+    for (int i = 1; i < 256; ++i) {
+        const double s = ((double)i - 0.5) / 255.0;
+        out[i] = (float)(s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4));
+    }
+}
 static uint8_t encode_srgb8(float c) {
+    if (!g_srgb_thr_ready) { orc_srgb_thresholds(g_srgb_thr); g_srgb_thr_ready = 1; }
     c = clampf(c, 0.0f, 1.0f);
-    float s = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 0.41666666f) - 0.055f;
-    return (uint8_t)(s * 255.0f + 0.5f);
+    uint32_t idx = 0;
+    for (uint32_t step = 128u; step; step >>= 1)
+        if (idx + step <= 255u && c >= g_srgb_thr[idx + step]) idx += step;
+    return (uint8_t)idx;
 }
 void orc_tonemap(const float *accum, uint32_t n, uint8_t *rgba8) {
     for (uint32_t i = 0; i < n; ++i) {

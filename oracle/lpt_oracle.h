@@ -83,6 +83,7 @@ void orc_raygen(const orc_render_params *p, uint32_t x, uint32_t y, float origin
 /* accum (sum,count) -> mean radiance rgba (a = count>0) and -> sRGB8 */
 void orc_resolve(const float *accum, uint32_t n_pixels, float *mean_rgba);
 void orc_tonemap(const float *accum, uint32_t n_pixels, uint8_t *rgba8);
+void orc_srgb_thresholds(float out[256]);   /* SPEC §13.2: linear value at which sRGB code i starts (out[0] = 0) */
 
 /* ---- denoiser path (BlitMode::DenoisedPathrace / Temporal; SPEC §15, reference render/asvgf.rs) */
 typedef struct orc_denoiser orc_denoiser;

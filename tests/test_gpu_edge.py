@@ -61,7 +61,7 @@ def test_empty_scene_is_all_environment(device):
     img, px, c, ref, ref_px, oc = _render_both(device, ps, os_, 70, 50, 3, 2, eye=(0, 0, 5), direction=(0, -0.2, -1))
     assert img.tobytes() == ref.tobytes() and (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
     assert c.closest == 70 * 50 * 2 and c.shaded == 0          # every primary ray leaves; nothing is shaded
-    assert np.abs(px.astype(int) - ref_px.astype(int)).max() <= 1
+    assert px.tobytes() == ref_px.tobytes()   # exact sRGB8 (SPEC §13.2)
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (33, 9), (97, 61), (31, 7), (257, 3)])
@@ -70,7 +70,7 @@ def test_ragged_sizes(device, w, h):
     img, px, c, ref, ref_px, oc = _render_both(device, ps, os_, w, h, 4, 2)
     assert img.shape == (h, w, 4) and img.tobytes() == ref.tobytes()
     assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
-    assert np.abs(px.astype(int) - ref_px.astype(int)).max() <= 1
+    assert px.tobytes() == ref_px.tobytes()   # exact sRGB8 (SPEC §13.2)
 
 
 @pytest.mark.parametrize("bounces", [1, 2, 17, 64])

@@ -413,3 +413,23 @@ def test_oracle_denoiser_properties(cornell_glb):
     d3 = orc.Denoiser(sc, w, h, T.VFOV, b)
     f_out = d3.frame(view, 1)
     assert d2.read()[2].tobytes() == d3.read()[2].tobytes() and t_out.tobytes() != f_out.tobytes()
+
+
+def test_srgb8_encode_is_the_correctly_rounded_oetf():
+    """SPEC §13.2: read_pixels' sRGB8 encode is a threshold-table search (no powf): against the OETF in binary64 it may differ only
+    where 255*s sits on a rounding boundary; 0 -> 0, 1 -> 255, monotone, NaN / negative -> 0, > 1 -> 255"""
+    rng = np.random.default_rng(5)
+    c = np.concatenate([rng.random(200000), rng.random(50000) * 0.01, [0.0, 1.0, 0.0031308, 0.5, 2.0, -1.0, np.nan, 1e-9]]).astype(np.float32)
+    acc = np.zeros((c.size, 4), np.float32)
+    acc[:, 0] = acc[:, 1] = acc[:, 2] = c
+    acc[:, 3] = 1.0
+    got = orc.tonemap(acc)[:, 0].astype(int)
+    cc = np.clip(np.nan_to_num(c.astype(np.float64), nan=0.0), 0.0, 1.0)
+    s = np.where(cc <= 0.0031308, 12.92 * cc, 1.055 * cc ** (1 / 2.4) - 0.055) * 255.0
+    want = np.floor(s + 0.5).astype(int)
+    off = got != want
+    assert np.all(np.abs(s[off] + 0.5 - np.round(s[off] + 0.5)) < 2e-3), "differs away from a rounding boundary"
+    assert off.mean() < 2e-3
+    assert got[-8] == 0 and got[-7] == 255 and got[-4] == 255 and got[-3] == 0 and got[-2] == 0
+    order = np.argsort(cc, kind="stable")
+    assert np.all(np.diff(got[order]) >= 0)
