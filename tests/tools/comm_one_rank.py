@@ -61,7 +61,29 @@ def main():
         for got, want in zip(shared.read_denoiser(), plain.read_denoiser()):
             assert got.tobytes() == want.tobytes()
     assert "torch" not in sys.modules
+    # the single-thread / several-communicators form: creation and the exchange inside a group (ncclGroupStart / End)
+    from loupiote_amd import _abi as A
+    L = A.lib()
+    shared.set_blit_mode(lp.BlitMode.Pahtrace)
+    plain.set_blit_mode(lp.BlitMode.Pahtrace)
     shared.set_comm(None)
+    assert L.lpt_comm_group_begin() == 0
+    comm2 = lp.Comm(dev, lp.Comm.unique_id(), 0, 1)
+    assert L.lpt_comm_group_end() == 0
+    shared.set_comm(comm2)
+    shared.set_resources(dev, sg, pr)
+    for r in (plain, shared):
+        r.reset_accumulation()
+        r.accumulate = True
+    for frame in range(2):
+        plain.raytrace(view)
+        shared.raytrace(view)
+        assert L.lpt_comm_group_begin() == 0
+        shared.exchange(lp.EXCHANGE_GATHER_TILES)
+        assert L.lpt_comm_group_end() == 0
+        assert shared.read_radiance().tobytes() == plain.read_radiance().tobytes(), frame
+    shared.set_comm(None)
+    comm2.close()
     for r in (plain, shared):
         r.close()
     comm.close()
