@@ -2,7 +2,9 @@
 (zero tests; arithmetic lives in the absent albedo_rtx) — *parity unpinned* — so
 the oracle is anchored to analytic known answers instead:
 PCG vectors, ray/triangle cases, BVH == brute force, polynomial accuracy, BSDF normalisation and
-reciprocity, an energy bound, a direct-lighting quadrature, and determinism / shard invariance."""
+reciprocity, an energy bound, a direct-lighting quadrature, an independent multi-bounce estimator (cosine sampling only, no
+light sampling, no MIS, the BSDF re-written in numpy) that must agree with the oracle's NEE + MIS path tracer in expectation,
+and determinism / shard invariance."""
 import ctypes as C
 import hashlib
 import os
@@ -539,7 +541,6 @@ def test_nee_mis_path_tracer_equals_an_independent_bsdf_only_estimator():
         tang /= np.linalg.norm(tang, axis=1, keepdims=True)
         bit = np.cross(N, tang)
         Ld = tang * (rr * np.cos(ph))[:, None] + bit * (rr * np.sin(ph))[:, None] + N * np.sqrt(1 - u1)[:, None]
-        f = np.stack([np_bsdf(base[m_], rough[m_], metal[m_], N[i][None], V[i][None].copy(), Ld[i][None].copy())[0] for i, m_ in enumerate(mat)]) if False else None
         f = np.zeros((si.size, 3))
         for m_ in (0, 1):
             sel = mat == m_
@@ -550,4 +551,4 @@ def test_nee_mis_path_tracer_equals_an_independent_bsdf_only_estimator():
         d[si] = Ld
     want = Lsum.mean(axis=0)
     err = Lsum.std(axis=0) / np.sqrt(n)
-    assert np.all(np.abs(got - want) <= 4 * err + 0.03 * want), (got, want, err)
+    assert np.all(np.abs(got - want) <= 4 * err + 0.01 * want), (got, want, err)   # measured: 0.18 % apart at 0.6 % standard error
