@@ -378,7 +378,7 @@ int lpt_device_stream(lpt_device *dev, void **stream) {
 int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     if (!sg) return LPT_OK;
     hipSetDevice(sg->dev->ordinal);
-    hipStreamSynchronize(sg->dev->stream);
+    hipDeviceSynchronize();   // renderers trace on their own streams: frames still in flight read what is freed here
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
                     sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -688,7 +688,7 @@ int lpt_probe_upload(lpt_device *dev, const uint8_t *rgbe8, uint32_t w, uint32_t
 int lpt_probe_destroy(lpt_probe *p) {
     if (!p) return LPT_OK;
     hipSetDevice(p->dev->ordinal);
-    hipStreamSynchronize(p->dev->stream);
+    hipDeviceSynchronize();   // frames in flight on the renderers' streams may still sample the probe
     if (p->rgbe) hipFree(p->rgbe);
     delete p;
     return LPT_OK;
