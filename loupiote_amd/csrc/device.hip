@@ -901,7 +901,11 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
         }
         e = hipMemcpy(r->srgb_thr, thr, sizeof thr, hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        const int st = fail(LPT_ERR_HIP, "renderer allocation failed: %s", hipGetErrorString(e));
+        lpt_renderer_destroy(r);   // frees whatever was allocated (every member starts out null)
+        return st;
+    }
     int st = alloc_frame_buffers(r);
     if (st != LPT_OK) { lpt_renderer_destroy(r); return st; }
     *out = r;
