@@ -375,6 +375,10 @@ def main():
                          "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
                                     "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation): a lower bound"},
                          "limits": limits_j,
+                         "binding_limit": ({"name": "valu_issue", "frac": limits_j["valu_issue"]["frac"], "source": limits_j.get("source"),
+                                            "note": "the kernel's algorithmic bytes come from L2 / Infinity Cache (traffic is 0.31 of the HBM roof): what binds it is the VALU issue "
+                                                    "rate of its instruction mix (PMC pass, tools/limits_from_pmc.py), not the HBM roof `frac` is quoted against"}
+                                           if limits_j and "valu_issue" in limits_j else None),
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
