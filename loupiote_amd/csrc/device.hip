@@ -2,9 +2,11 @@
 //
 // Host orchestration of one frame follows Renderer::raytrace
 // (reference crates/lib/src/renderer.rs:392-549): pass order, the seed / bounces /
-// frame_count protocol and the accumulate flag.  Everything is enqueued on ONE HIP
-// stream owned by the device handle and nothing here waits for the GPU except the
-// read-back calls (the reference's only blocking point is read_pixels, :791).
+// frame_count protocol and the accumulate flag.  A renderer enqueues on its own HIP stream (accumulation,
+// filter passes, reads, the frame exchange: in call order) and on the streams of its wavefront lanes (the
+// traversal / shading of consecutive raytrace() calls, overlapped); nothing here waits for the GPU except the
+// read-back calls (the reference's only blocking point is read_pixels, :791) and scene edits.
+// Also here: the multi-GPU frame exchange (plain RCCL: lpt_comm_*, lpt_renderer_exchange).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
