@@ -242,6 +242,11 @@ int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t width, uint32
  * LPT_ERR_FILE_NOT_FOUND when the data is not a decodable "-Y H +X W" 32-bit_rle_rgbe image. */
 int lpt_decode_hdr(const uint8_t *data, size_t size, uint8_t *rgbe8, size_t capacity, uint32_t *width, uint32_t *height);
 
+/* replaces: the `image::io::Reader::open(path).decode()` step of ApplicationContext::load_blue_noise
+ * (crates/standalone/src/app.rs:116-132): PNG or Huffman-coded JPEG bytes -> RGBA8 pixels, rows top to bottom (channels the
+ * file lacks are 0, as in the glTF image path), e.g. for lpt_renderer_upload_noise.  Call with rgba8 == NULL to get the size. */
+int lpt_decode_image(const uint8_t *data, size_t size, uint8_t *rgba8, size_t capacity, uint32_t *width, uint32_t *height);
+
 /* new (the linear-radiance counterpart of lpt_write_png): RGBA float rows (e.g. lpt_renderer_read_radiance)
  * as a Radiance RGBE .hdr file (alpha dropped, negative / NaN -> 0).  row_floats = floats between row starts (>= 4*width). */
 int lpt_write_hdr(const char *path, const float *rgba, uint32_t width, uint32_t height, size_t row_floats);

@@ -4,4 +4,4 @@ The product is ``libloupiote_hip.so`` (C ABI in include/lpt.h, HIP kernels for g
 this package is the thin host-side mirror of the reference's `loupiote-core` crate."""
 from ._abi import EXCHANGE_GATHER_TILES, EXCHANGE_REDUCE, INVALID_INDEX, LIB_PATH, LIGHT_BIT  # noqa: F401
 from .api import (BlitMode, CameraController, Comm, Device, Error, ProbeGPU, Renderer, Scene, SceneGPU,  # noqa: F401
-                  default_light, load_env, load_env_path, loaders, save_radiance, save_screenshot)
+                  decode_image, default_light, load_blue_noise, load_env, load_env_path, loaders, save_radiance, save_screenshot)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "lpt_load_gltf": (_i, [_vp, _vp, _sz]),
     "lpt_load_gltf_path": (_i, [_vp, C.c_char_p]),
     "lpt_decode_hdr": (_i, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "lpt_decode_image": (_i, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lpt_write_hdr": (_i, [C.c_char_p, _vp, _u32, _u32, _sz]),
     "lpt_write_png": (_i, [C.c_char_p, _vp, _u32, _u32, _sz]),
     "lpt_scene_upload": (_i, [_vp, _vp, _pvp]),

@@ -499,6 +499,24 @@ def load_env(data):
     return out
 
 
+def decode_image(data):
+    """PNG / JPEG bytes -> (h, w, 4) uint8 RGBA (lpt_decode_image): the decoding half of load_blue_noise (app.rs:116-132)"""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(A.lib().lpt_decode_image(A.ptr(buf), buf.size, None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    _check(A.lib().lpt_decode_image(A.ptr(buf), buf.size, A.ptr(out), out.size, C.byref(w), C.byref(h)))
+    return out
+
+
+def load_blue_noise(renderer, path):
+    """ApplicationContext::load_blue_noise (crates/standalone/src/app.rs:116-132): image file -> Renderer::upload_noise_texture"""
+    with open(path, "rb") as f:
+        px = decode_image(f.read())
+    renderer.upload_noise_texture(px, px.shape[1], px.shape[0], px.shape[1] * 4)
+    return px
+
+
 def load_env_path(path):
     with open(path, "rb") as f:
         return load_env(f.read())

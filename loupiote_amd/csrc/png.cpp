@@ -282,3 +282,24 @@ extern "C" int lpt_write_png(const char *path, const uint8_t *rgba8, uint32_t wi
     fclose(f);
     return ok ? LPT_OK : lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: short write to %s", path);
 }
+
+// replaces: the `image::io::Reader::open(path).decode()` half of ApplicationContext::load_blue_noise
+// (crates/standalone/src/app.rs:116-132): PNG / JPEG bytes -> RGBA8 pixels for lpt_renderer_upload_noise (or any other use).
+extern "C" int lpt_decode_image(const uint8_t *data, size_t size, uint8_t *rgba8, size_t capacity, uint32_t *width, uint32_t *height) {
+    if (!data || !width || !height) return lpt::fail(LPT_ERR_INVALID_ARG, "lpt_decode_image: null");
+    lpt::Image im;
+    bool ok = false;
+    try {
+        ok = lpt::decode_png(data, size, im) || lpt::decode_jpeg(data, size, im);
+    } catch (const std::exception &e) {
+        return lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: %s", e.what());
+    }
+    if (!ok) return lpt::fail(LPT_ERR_FILE_NOT_FOUND, "file not found: neither a decodable PNG nor a Huffman-coded JPEG");
+    *width = im.width; *height = im.height;
+    if (rgba8) {
+        if (capacity < im.rgba8.size()) return lpt::fail(LPT_ERR_INVALID_ARG, "lpt_decode_image: buffer of %zu bytes, %zu needed", capacity, im.rgba8.size());
+        memcpy(rgba8, im.rgba8.data(), im.rgba8.size());
+    }
+    return LPT_OK;
+}
+

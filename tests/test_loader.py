@@ -376,3 +376,18 @@ def test_hdr_writer_round_trip(tmp_path):
     assert px.tobytes() == want.tobytes()
     dec = px[..., :3].astype(np.float64) * np.exp2(px[..., 3:4].astype(np.float64) - 136.0)
     assert np.all(np.abs(dec - clean) <= m[..., None] / 128.0 + 1e-30)
+
+
+def test_decode_image_export(tmp_path):
+    """lpt_decode_image: the decoder behind load_blue_noise (app.rs:116-132) — PNG exact, JPEG within the loader's tolerance"""
+    from PIL import Image
+    rng = np.random.default_rng(8)
+    rgba = rng.integers(0, 256, (33, 47, 4), dtype=np.uint8)
+    assert np.array_equal(lp.decode_image(png_bytes(rgba)), rgba)
+    rgb = _smooth_rgb()
+    got = lp.decode_image(_jpeg(rgb, quality=92, subsampling=0, progressive=True))
+    ref = np.asarray(Image.open(io.BytesIO(_jpeg(rgb, quality=92, subsampling=0, progressive=True))).convert("RGB")).astype(int)
+    assert got.shape == (97, 131, 4) and np.abs(got[..., :3].astype(int) - ref).max() <= 4
+    with pytest.raises(lp.Error) as e:
+        lp.decode_image(b"not an image")
+    assert e.value.kind == "FileNotFound"
