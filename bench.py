@@ -107,6 +107,14 @@ def cpu_baseline(desc, view, threads):
                       "workload with the seeds of the GPU frame's 1st, 2nd ... sample (%.1f Mrays in %.1f s); a reported baseline, not a target" % (frames, rays / 1e6, secs)}
 
 
+def baseline_metric():
+    """the metric string exactly as BASELINE.json spells it"""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "Mrays/s (+ ms/frame) at 1920\u00d71080, 4 spp, Sponza; 1/2/4/8 GPU"
+
+
 def load_profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -339,7 +347,7 @@ def main():
         traffic_j = load_profile_json("traffic.json") or {}
         limits_j = load_profile_json("limits.json")
         out = {
-            "metric": "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza; 1/2/4/8 GPU",
+            "metric": baseline_metric(),
             "value": (closest + shadow) / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
