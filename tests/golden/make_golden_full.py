@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Generates tests/golden/full_configs.npz: ORACLE vectors at the FULL sizes of BASELINE.json configs 3, 4 and 5
-(SURVEY §8c "Golden vectors / fixtures"), so that the -m gpu tests pin the HIP path to committed numbers at the
+(SURVEY §8c "Golden vectors / fixtures"; config 2 as well), so that the -m gpu tests pin the HIP path to committed numbers at the
 sizes the bench runs, not only to a live oracle at reduced sizes.
 
+  cfg2  cornell-box.glb, 1024x1024, 4 spp, depth 8
   cfg3  DamagedHelmet stand-in + sky probe, 1920x1080, 8 spp, depth 8
   cfg4  Sponza stand-in (the bench workload), 1920x1080, 4 spp, depth 8
   cfg5p the same scene, 3840x2160, depth 8: the first 2 of the 64 progressive samples
@@ -44,6 +45,17 @@ def record(out, key, img, cnt=None, extra=None):
 def main():
     out = {}
     t0 = time.time()
+    path = os.path.join(ROOT, "tests", "golden", "full_configs.npz")
+    if "--only-cfg2" in sys.argv:   # add / refresh config 2 without re-rendering the big frames
+        out = dict(np.load(path))
+    # config 2: cornell-box.glb, 1024x1024, 4 spp, depth 8 (build-defined camera / light / probe of loupiote_amd.testing)
+    glb = open(os.path.join(ROOT, "tests", "golden", "cornell-box.glb"), "rb").read()
+    img, cnt = harness.render_oracle(glb, 1024, 1024, 8, 4)
+    record(out, "cfg2", img, cnt)
+    if "--only-cfg2" in sys.argv:
+        np.savez_compressed(path, **out)
+        print("done in %.0f s" % (time.time() - t0))
+        return
     helmet = scenes.synthetic_helmet()
     osc = orc.OracleScene.from_scene(harness.to_oracle(helmet), probe=helmet["probe"])
     view = T.look(helmet["camera"]["origin"], helmet["camera"]["direction"])
