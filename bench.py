@@ -2,66 +2,186 @@
 """bench.py — Mrays/s of the path-tracing hot path on N MI355X (one process per GPU).
 
 Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponza"):
-  synthetic_atrium(seed=2) — the Sponza STAND-IN (the real asset is absent) —
-  1920x1080, 4 spp (= 4 raytrace() calls with accumulate), path depth 8, camera = the reference's
-  start pose.  A FRAME = reset_accumulation(); accumulate=true; 4 x Renderer::raytrace(view) — issued as
-  lpt_renderer_raytrace_n(view, 4), the bit-identical batched form; for N>1 followed by
-  lpt_renderer_exchange (native RCCL inside the library: owned-tile gather to rank 0, or --exchange reduce).
-  A STEP = FRAMES_PER_STEP (10) such frames, so that the driver's `--steps 20` times about 2 s instead of 0.2 s.
-  Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
-  Consecutive frames rotate over three renderers with their own HIP streams (--pipeline 3: three frames in flight,
-  triple buffering; four for the smaller wavefronts of a tile shard), so the tail of frame k (and its exchange) overlaps the heads of the next frames; every frame is
-  still one complete frame.  GPU_MAX_HW_QUEUES is raised to 8 (ROCm default 4, of which the streams here got two):
-  with fewer hardware queues than streams the frames serialise again.
-  N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N), per-GPU work shrinks as
-  N grows ("strong" scaling of one frame).  torch.distributed (gloo) is the control plane only — rendezvous of the
-  128-byte RCCL id, barriers, the max over ranks; the data path is lpt_renderer_exchange.
+  synthetic_atrium(seed=2) — the Sponza STAND-IN (the real asset is absent) at the sizes §8d gives it
+  (262,144 triangles, 20 x 1024^2 textures = 80 MB of texels, 25 materials) — 1920x1080, 4 spp, path depth 8, camera = the
+  reference's start pose.  Inputs (scene, BVH, probe, textures) are resident in HBM before the timed region.
 
-value = (closest-hit + shadow rays traced by all ranks in the K timed steps) / wall time, in
-Mrays/s, with barrier + torch.cuda.synchronize() on both sides and the MAX over ranks.
+`value` is measured over the span SURVEY §8d defines and crates/standalone issues (app.rs:297-337), on ONE renderer per GPU:
+    per FRAME:  reset_accumulation(); accumulate = true; 4 x Renderer::raytrace(view); [N>1: lpt_renderer_exchange];
+                read_radiance()  (rank 0; blocking, into page-locked host memory; the other ranks synchronise)
+  raytrace() RECORDS (record-then-submit, include/lpt.h): the four calls of a frame are launched by the next submission
+  point as one wavefront of 4 samples per pixel, bit-identical to four separate launches.
+  A STEP = FRAMES_PER_STEP (10) such frames, so that the driver's `--steps 20` times about 2.5 s instead of 0.25 s.
+  value = (closest-hit + shadow rays traced by all ranks in the K timed steps) / wall time, in Mrays/s, with barrier +
+  torch.cuda.synchronize() on both sides and the MAX over ranks.
+  N>1: frames shard by interleaved 32x8 pixel tiles (tile id mod N): per-GPU work shrinks as N grows ("strong" scaling of one
+  frame).  The exchange is native RCCL inside the library (owned-tile gather to rank 0, or --exchange reduce);
+  torch.distributed (gloo) is the control plane only — rendezvous of the 128-byte RCCL ids, barriers, the max over ranks.
 
-Besides `value` (a THROUGHPUT figure: three frames in flight, batched samples) the line carries
-  latency_ms  one frame alone (raytrace_n(view, 4) + synchronize), nothing else on the GPU;
-  drop_in     what the unchanged caller gets (crates/standalone, app.rs:297-318; SURVEY §8d span): ONE renderer,
-              4 x raytrace() + read_radiance() (33 MB device -> host) per frame, no raytrace_n;
-  roofline    k_trace: algorithmic bytes per launch / the UN-OVERLAPPED launch time (HIP events on the renderer's stream,
-              nothing co-running: what rocprofv3's serialised kernel trace sees) / 8 TB/s; `overlapped` = the same over the
-              timed region, where a launch shares the CUs with two other frames; `limits` = the PMC-derived ceilings;
+Launch: `python bench.py --gpus N ...` starts its own N ranks (child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+BEFORE anything touches a GPU, relays rank 0's JSON line and exits non-zero with the failing rank's stderr if a rank dies;
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set) it is one of the ranks.
+
+Besides `value` the line carries
+  throughput  --pipeline P renderers in flight (own HIP streams and, for N>1, own RCCL communicators), the 4 spp of a frame as
+              raytrace_n(view, 4), no read-back: what the hardware sustains when frames overlap (round 2's `value`);
+  latency_ms  one frame alone without the read-back;
+  roofline    k_trace: algorithmic bytes per launch / the launch time (HIP events on the stream the kernel runs on; one frame
+              at a time, nothing co-running) / 8 TB/s, with the PMC-derived limits of profiles/limits.json;
+  rccl        (N>1) what RCCL itself reports for the communicator, the exchange time per frame (HIP events around
+              lpt_renderer_exchange on rank 0), per-rank ray counts, and whether rank 0's presented frame was complete;
   cpu_baseline  the oracle ("port") on the host cores, bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # read by the HIP runtime at initialisation: one hardware queue per stream
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single-node control plane; the box's hostname may not resolve
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import loupiote_amd as lp  # noqa: E402
-
-if not os.path.exists(lp.LIB_PATH):  # the built library normally travels with the tree; a fresh checkout builds it (hipcc, ~1 min)
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        from loupiote_amd import build as _build
-        _build.build()
-    else:  # one builder per node; the other ranks wait for the file
-        _t0 = time.time()
-        while not os.path.exists(lp.LIB_PATH) and time.time() - _t0 < 900:
-            time.sleep(1.0)
-        time.sleep(2.0)
-from loupiote_amd import scenes, testing as T  # noqa: E402
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 4, 8
 FRAMES_PER_STEP = 10
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the throughput / latency measurements (experiments)")
+    ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
+    ap.add_argument("--texture-size", type=int, default=1024, help="experiments only (SURVEY §8d: 1024)")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
+    ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, communicator, exchange) even with one rank")
+    ap.add_argument("--exchange", choices=["gather", "reduce"], default="gather",
+                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv) or the dense ncclReduce of the accumulation buffer")
+    ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
+                    "RCCL communicator); default 3 on one GPU, 4 for tile shards")
+    ap.add_argument("--eager", action="store_true", help="experiments: every raytrace() launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour)")
+    ap.add_argument("--pageable", action="store_true", help="experiments: read_radiance() into pageable host memory")
+    ap.add_argument("--spawn-dry-run", action="store_true", help="start the ranks and rendezvous over gloo only: no GPU is touched (CPU test of the launcher)")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="seconds the self-started ranks may take")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, relay rank 0's JSON line.
+    Runs before anything initialises a GPU (torch.cuda.device_count() does not, on this image); never exec()s."""
+    n = args.gpus
+    if not args.spawn_dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node — cannot start %d ranks (one process per GPU)\n" % (n, have, n))
+            return 3
+    env_base = dict(os.environ)
+    env_base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "LOCAL_WORLD_SIZE": str(n)})
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="lpt_bench_")
+    for rank in range(n):
+        env = dict(env_base)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank)})
+        err = open(os.path.join(tmp, "rank%d.err" % rank), "w+")
+        out = subprocess.PIPE if rank == 0 else open(os.path.join(tmp, "rank%d.out" % rank), "w+")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err, text=True))
+        logs.append(err)
+
+    def tail(rank, nbytes=4000):
+        logs[rank].flush()
+        logs[rank].seek(0)
+        return logs[rank].read()[-nbytes:]
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t0 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t0 < 10:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+
+    # rank 0's stdout is read to the end by communicate() in a thread-free way: poll the others meanwhile
+    import threading
+    box = {}
+    reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0 = time.time()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > args.spawn_timeout:
+            failed = -1
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        stop_all()
+        if failed < 0:
+            sys.stderr.write("bench.py --gpus %d: the ranks did not finish within %.0f s; stopped them\n" % (n, args.spawn_timeout))
+            for i in range(n):
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (i, tail(i, 1500)))
+            return 4
+        sys.stderr.write("bench.py --gpus %d: rank %d exited with code %s\n---- rank %d stderr (tail) ----\n%s\n" % (n, failed, procs[failed].returncode, failed, tail(failed)))
+        return procs[failed].returncode or 1
+    reader.join(timeout=10)
+    lines = [l for l in (box.get("out") or "").splitlines() if l.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py --gpus %d: rank 0 printed no JSON line\n---- rank 0 stderr (tail) ----\n%s\n" % (n, tail(0)))
+        return 5
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def dry_run(args):
+    """the launcher's CPU test: the ranks meet over gloo and rank 0 reports who came; no GPU, no library"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("LPT_BENCH_TEST_DIE_RANK") == str(rank):   # launcher test: a rank that dies before the rendezvous
+        sys.stderr.write("rank %d: LPT_BENCH_TEST_DIE_RANK set, exiting with code 7\n" % rank)
+        return 7
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = rank + 1
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": [int(x) - 1 for x in t.tolist()], "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def effective_cpus():
     """host threads this process may actually run on: the cgroup CPU quota when there is one (the GPU boxes expose 256
     hardware threads but grant 16 CPUs of time: oversubscribing them makes the oracle 40 % slower), else the affinity mask"""
@@ -81,7 +201,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(desc, view, threads):
+def cpu_baseline(desc, view, threads, T):
     """The CPU oracle ("port") timed on the host cores on a bounded sample of the same workload:
     whole 1920x1080 frames of 1 spp each (the same seeds the GPU frame uses for its 1st, 2nd ... sample),
     as many as fit in ~12 s of wall time."""
@@ -112,7 +232,7 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
-        return "Mrays/s (+ ms/frame) at 1920\u00d71080, 4 spp, Sponza; 1/2/4/8 GPU"
+        return "Mrays/s (+ ms/frame) at 1920×1080, 4 spp, Sponza; 1/2/4/8 GPU"
 
 
 def load_profile_json(name):
@@ -125,37 +245,32 @@ def load_profile_json(name):
     return None
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ one rank
+def run(args):
     global WIDTH, HEIGHT, SPP
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip latency / drop_in / solo measurements (experiments)")
-    ap.add_argument("--scene", default="atrium")
-    ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
-    ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--spp", type=int, default=SPP)
-    ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
-    ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
-    ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, communicator, exchange) even with one rank")
-    ap.add_argument("--exchange", choices=["gather", "reduce"], default="gather",
-                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv) or the dense ncclReduce of the accumulation buffer")
-    ap.add_argument("--pipeline", type=int, default=0, help="renderers (each with its own HIP stream) that take consecutive frames in turn; "
-                    "default 3 on one GPU, 4 for tile shards (a 1/8 shard: 1.79 ms per frame with 3, 1.70 with 4, 1.71 with 6, 1.84 with 8 in flight)")
-    ap.add_argument("--no-batch", action="store_true", help="4 separate raytrace() calls instead of raytrace_n(view, 4)")
-    args = ap.parse_args()
-    WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
-    BATCH = not args.no_batch
-    FPS = max(1, args.frames_per_step)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import loupiote_amd as lp
 
+    if not os.path.exists(lp.LIB_PATH):  # the built library normally travels with the tree; a fresh checkout builds it (hipcc, ~1 min)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            from loupiote_amd import build as _build
+            _build.build()
+        else:  # one builder per node; the other ranks wait for the file
+            _t0 = time.time()
+            while not os.path.exists(lp.LIB_PATH) and time.time() - _t0 < 900:
+                time.sleep(1.0)
+            time.sleep(2.0)
+    from loupiote_amd import scenes, testing as T
+
+    WIDTH, HEIGHT, SPP = args.width, args.height, args.spp
+    FPS = max(1, args.frames_per_step)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -164,23 +279,31 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only (id rendezvous, barriers, max over ranks)
 
     dev = lp.Device(local_rank)
-    comm = None
+    P = args.pipeline if args.pipeline > 0 else (4 if (world > 1 or args.emulate_shard > 1) else 3)
+    extras = not args.no_extras
+    comms = []
     if use_dist:
-        box = [lp.Comm.unique_id() if rank == 0 else None]
+        # one communicator for the timed renderer + one per pipelined renderer of the throughput measurement: RCCL serialises
+        # the operations of ONE communicator, so frames in flight must not share one
+        n_comms = 1 + (P if extras else 0)
+        box = [[lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        comm = lp.Comm(dev, box[0], rank, world)   # ncclCommInitRank inside the library (RCCL over xGMI)
+        for uid in box[0]:
+            comms.append(lp.Comm(dev, uid, rank, world))   # ncclCommInitRank inside the library (RCCL over xGMI)
     xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
-    desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"))
+    desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"), texture_size=args.texture_size)
+    tex_bytes = int(sum(im.size for im in desc["images"]))
     scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, dev, gpu_build=bool(os.environ.get("LPT_BENCH_GPU_BUILD")))
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
-    P = args.pipeline if args.pipeline > 0 else (4 if (world > 1 or args.emulate_shard > 1) else 3)
 
-    def make_renderer(lanes=1):
+    def make_renderer(comm=None, lanes=None):
         rr = lp.Renderer(dev, (WIDTH, HEIGHT))
         if lanes:
-            rr.set_lanes(lanes)          # the throughput loop overlaps frames of DIFFERENT renderers: one wavefront lane each
+            rr.set_lanes(lanes)
+        if args.eager:
+            rr.set_max_fused(1)
         rr.downsample_factor = 1.0
         rr.resize(dev, sg, probe, (WIDTH, HEIGHT))
         rr.set_max_bounces(DEPTH)
@@ -193,75 +316,78 @@ def main():
             rr.set_resources(dev, sg, probe)
         return rr
 
-    rs = [make_renderer() for _ in range(P)]
-    frame_no = [0]
-
-    def frame(r=None):
-        if r is None:
-            r = rs[frame_no[0] % P]
-            frame_no[0] += 1
-        r.reset_accumulation()
-        r.accumulate = True
-        if BATCH:
-            r.raytrace_n(view, SPP)      # == SPP x { raytrace(view); accumulate = true } as one wavefront
-        else:
-            for _ in range(SPP):
-                r.raytrace(view)
-        if comm is not None:
-            r.exchange(xmode)            # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
-
-    def step():
-        for _ in range(FPS):
-            frame()
-
-    def fence():
+    def fence(renderers):
         if use_dist:
             dist.barrier()
-        for rr in rs:
+        for rr in renderers:
             rr.synchronize()
         torch.cuda.synchronize()
 
+    # ================================================================== value: the SURVEY §8d span on ONE renderer
+    r = make_renderer(comms[0] if comms else None)
+    dst = None if args.pageable else lp.pinned_array((HEIGHT, WIDTH, 4))   # page-locked read-back destination (lpt_host_alloc)
+    last = {}
+
+    def span_frame():
+        r.reset_accumulation()
+        r.accumulate = True                      # app.rs:318
+        for _ in range(SPP):
+            r.raytrace(view)                     # records; the four calls leave as one wavefront
+        if comms:
+            r.exchange(xmode)                    # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
+        if rank == 0:
+            last["img"] = r.read_radiance(out=dst)   # blocking: the end of the §8d span
+        else:
+            r.synchronize()
+
     for _ in range(args.warmup):
-        step()
-    fence()
-    for rr in rs:
-        rr.reset_ray_counts()
-        rr.enable_timings(True)
-    fence()
+        for _ in range(FPS):
+            span_frame()
+    fence([r])
+    r.reset_ray_counts()
+    r.enable_timings(True)
+    fence([r])
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    fence()
+        for _ in range(FPS):
+            span_frame()
+    fence([r])
     elapsed = time.perf_counter() - t0
-    timings = {}
-    closest_l = shadow_l = shaded_l = 0
-    for rr in rs:
-        for k, v in rr.timings().items():
-            t0_, n0_ = timings.get(k, (0.0, 0))
-            timings[k] = (t0_ + v[0], n0_ + v[1])
-        rr.enable_timings(False)
-        c_ = rr.ray_counts()
-        closest_l += c_.closest; shadow_l += c_.shadow; shaded_l += c_.shaded
+    timings = r.timings()
+    r.enable_timings(False)
+    c_ = r.ray_counts()
+    closest_l, shadow_l, shaded_l = c_.closest, c_.shadow, c_.shaded
+    n_frames = args.steps * FPS
 
     tl = torch.tensor([elapsed], dtype=torch.float64)
     rays = torch.tensor([closest_l, shadow_l, shaded_l], dtype=torch.float64)
+    per_rank = [float(closest_l + shadow_l)]
     if use_dist:
         dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([float(closest_l + shadow_l)], dtype=torch.float64))
+        per_rank = [float(g.item()) for g in gathered]
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tl.item())
     closest, shadow, shaded = [float(x) for x in rays.tolist()]
-    n_frames = args.steps * FPS
+
+    # the presented frame of the last timed step: every pixel of the frame with its 4 samples, on rank 0
+    frame_ok = None
+    checksum = None
+    if rank == 0:
+        img = last["img"]
+        frame_ok = bool(np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img)) and float(img[..., :3].mean()) > 0.0)
+        checksum = float(np.float64(img[..., :3].sum()))
 
     # ---- roofline of the dominant kernel (k_trace), this rank: algorithmic bytes per launch
     # = closest rays * (32 B ray read + 16 B hit write + N*80 B nodes + T*48 B triangles)
     # + shadow rays * (32 B ray read + 4 B + Ns*80 B + Ts*48 B), with N, T, Ns, Ts (mean nodes visited /
     # triangles tested per ray) measured by the stats variant of the same kernel on the same frame,
     # outside the timed region.
-    r = rs[0]
     r.enable_stats(True)
     r.reset_ray_counts()
-    frame(r)
-    fence()
+    span_frame()
+    fence([r])
     st = r.ray_counts()
     r.enable_stats(False)
     n_bar = st.nodes / max(st.closest, 1)
@@ -280,69 +406,94 @@ def main():
         byts = (cl * b_ray + sh * b_sh) / max(launches, 1)
         return avg, launches, byts, (byts / (avg * 1e-3) / 1e9 if avg > 0 else 0.0)
 
-    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l, shadow_l)
-    rays_per_launch = (closest_l + shadow_l) / max(o_launches, 1)
-    extras = not args.no_extras
-    # the same launches with nothing co-running: SOLO_FRAMES frames on renderer 0 alone (HIP events on its stream)
-    SOLO_FRAMES = 3
-    r.reset_ray_counts()
-    r.enable_timings(True)
-    for _ in range(SOLO_FRAMES):
-        frame(r)
-        fence()
-    solo_t = r.timings()
-    r.enable_timings(False)
-    sc_ = r.ray_counts()
-    s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest, sc_.shadow)
+    # the timed region runs one frame at a time on one renderer: its launches ARE the un-overlapped launches
+    s_avg, s_launches, s_bytes, s_achieved = trace_stage(timings, closest_l, shadow_l)
+    rays_per_launch = (closest_l + shadow_l) / max(s_launches, 1)
+    exchange_ms = timings.get("exchange", (0.0, 0))
 
-    # N>1 (or --force-dist): rank 0's PRESENTED frame after an exchange must hold every pixel of the frame with its 4 samples
-    exchange_ok = None
-    if comm is not None:
-        frame(r)
-        fence()
-        if rank == 0:
-            img = r.read_radiance()
-            exchange_ok = bool(np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img)) and float(img[..., :3].mean()) > 0.0)
-
-    latency = drop_in = None
+    # ---- latency: one frame alone, host call to completion, no read-back
+    latency = None
     if extras:
-        # ---- latency: one frame alone, host call to completion
         lat = []
         for _ in range(7):
-            fence()
+            fence([r])
             t1 = time.perf_counter()
-            frame(r)
+            r.reset_accumulation()
+            r.accumulate = True
+            for _ in range(SPP):
+                r.raytrace(view)
+            if comms:
+                r.exchange(xmode)
             r.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
         latency = {"min": lat[0], "median": lat[len(lat) // 2], "frames": len(lat),
-                   "what": "one frame alone: reset_accumulation + raytrace_n(view, 4)%s + stream synchronize" % (" + exchange" if comm is not None else "")}
-        # ---- drop-in: the unchanged caller's protocol on ONE renderer (SURVEY §8d span: raytrace() x spp ... read_radiance())
-        if comm is None and args.emulate_shard <= 1:
-            DROP_FRAMES = 10
-            fence()
-            rd = make_renderer(lanes=0)          # a renderer as the library hands it out (default: 2 wavefront lanes)
-            for _ in range(2):                   # warm-up: the lanes allocate their ray buffers on first use
-                for _ in range(SPP):
-                    rd.raytrace(view)
-            rd.synchronize()
-            rd.reset_ray_counts()
-            t1 = time.perf_counter()
-            for _ in range(DROP_FRAMES):
-                rd.reset_accumulation()
-                rd.accumulate = True
-                for _ in range(SPP):
-                    rd.raytrace(view)
-                img = rd.read_radiance()         # blocking; 33 MB device -> host inside the span
-            dt = time.perf_counter() - t1
-            dc = rd.ray_counts()
-            rd.close()
-            drop_in = {"ms_per_frame": dt / DROP_FRAMES * 1e3, "value": (dc.closest + dc.shadow) / dt / 1e6, "unit": "Mrays/s", "frames": DROP_FRAMES,
-                       "what": "ONE renderer with the library's defaults, per frame: reset_accumulation; 4 x raytrace(view) (no raytrace_n); read_radiance() "
-                               "(k_resolve + 33 MB D2H into pageable host memory) — the span SURVEY §8d defines and crates/standalone issues (app.rs:297-318).  "
-                               "The renderer's two wavefront lanes let consecutive raytrace() calls overlap (18.2 ms with one lane)",
-                       "checksum": float(np.float64(img[..., :3].sum()))}
+                   "what": "one frame alone: reset_accumulation + 4 x raytrace(view)%s + stream synchronize (no read-back)" % (" + exchange" if comms else "")}
+    r.close()
 
+    # ================================================================== throughput: P renderers in flight, batched samples, no read-back
+    throughput = None
+    if extras:
+        rs = [make_renderer(comms[1 + k] if comms else None, lanes=1) for k in range(P)]
+        T_STEPS = max(2, min(args.steps, 6))
+        no = [0]
+
+        def tp_frame():
+            rr = rs[no[0] % P]
+            no[0] += 1
+            rr.reset_accumulation()
+            rr.accumulate = True
+            rr.raytrace_n(view, SPP)      # == SPP x { raytrace(view); accumulate = true } as one wavefront, submitted at once
+            if comms:
+                rr.exchange(xmode)
+
+        for _ in range(2 * FPS):
+            tp_frame()
+        fence(rs)
+        for rr in rs:
+            rr.reset_ray_counts()
+            rr.enable_timings(True)
+        fence(rs)
+        t1 = time.perf_counter()
+        for _ in range(T_STEPS * FPS):
+            tp_frame()
+        fence(rs)
+        dt = time.perf_counter() - t1
+        tm = {}
+        tp_rays = 0
+        for rr in rs:
+            for k, v in rr.timings().items():
+                a, b = tm.get(k, (0.0, 0))
+                tm[k] = (a + v[0], b + v[1])
+            rr.enable_timings(False)
+            cc = rr.ray_counts()
+            tp_rays += cc.closest + cc.shadow
+        tt = torch.tensor([dt], dtype=torch.float64)
+        tr = torch.tensor([float(tp_rays)], dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        o_avg, o_launches, o_bytes, o_achieved = trace_stage(tm, closest_l / n_frames * T_STEPS * FPS, shadow_l / n_frames * T_STEPS * FPS)
+        throughput = {"value": float(tr.item()) / float(tt.item()) / 1e6, "unit": "Mrays/s", "ms_per_frame": float(tt.item()) / (T_STEPS * FPS) * 1e3,
+                      "frames": T_STEPS * FPS, "frames_in_flight": P, "communicators": P if comms else 0,
+                      "what": "%d renderers take the frames in turn (own HIP streams%s); frame = reset_accumulation + raytrace_n(view, 4)%s; no read-back — "
+                              "round 2's headline figure" % (P, ", own RCCL communicators" if comms else "", " + lpt_renderer_exchange" if comms else ""),
+                      "k_trace_overlapped": {"avg_launch_ms": o_avg, "launches": o_launches, "frac": o_achieved / HBM_PEAK_GBS,
+                                             "note": "HIP events around every k_trace launch while %d frames share the chip: a scheduling figure, not a kernel figure" % P},
+                      "stage_ms_per_frame": {k: v[0] / (T_STEPS * FPS) for k, v in tm.items()}}
+        for rr in rs:
+            rr.close()
+
+    rccl = None
+    if comms:
+        rk, nr = comms[0].info()
+        rccl = {"rccl_nranks": nr, "rccl_rank": rk, "communicators_per_rank": len(comms),
+                "exchange_frame_complete_on_rank0": frame_ok,
+                "exchange_ms_per_frame_rank0": exchange_ms[0] / max(exchange_ms[1], 1), "exchanges_timed": exchange_ms[1],
+                "exchange_ms_what": "HIP events on rank 0's renderer stream from the pack kernel to the end of the unpack: includes waiting for the slowest rank's tiles",
+                "per_rank_rays": per_rank, "mode": args.exchange}
+
+    out = None
     if rank == 0:
         traffic_j = load_profile_json("traffic.json") or {}
         limits_j = load_profile_json("limits.json")
@@ -359,55 +510,49 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in, 262144 tris], 1920x1080, 4 spp, depth 8, "
-                                   "camera (-10,1,0)->(1,0.35,0); frame = raytrace_n(view,4) == 4 x raytrace%s; step = %d frames, %d frames in flight "
-                                   "(throughput; see latency_ms and drop_in for one frame alone / the unbatched protocol with read-back)"
-                                   % (" + lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", FPS, P),
-                       "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed,
-                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none", "exchange_frame_complete_on_rank0": exchange_ok,
+            "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in: %d triangles, %d textures = %.1f MB of texels, %d materials], %dx%d, %d spp, depth %d, "
+                                   "camera (-10,1,0)->(1,0.35,0); frame = the SURVEY 8d span on one renderer per GPU: reset_accumulation; %d x raytrace(view) "
+                                   "(recorded, submitted as one wavefront)%s; read_radiance() into %s host memory on rank 0; step = %d frames"
+                                   % (accel.triangles, len(desc["images"]), tex_bytes / 1e6, len(desc["materials"]), WIDTH, HEIGHT, SPP, DEPTH, SPP,
+                                      "; lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", "pageable" if args.pageable else "page-locked", FPS),
+                       "texture_bytes": tex_bytes, "textures": len(desc["images"]), "materials": len(desc["materials"]),
+                       "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed, "submission": "eager" if args.eager else "record-then-submit",
+                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
-                       "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded},
+                       "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum},
             "ms_per_frame": elapsed / n_frames * 1e3,
+            "throughput": throughput,
             "latency_ms": latency,
-            "drop_in": drop_in,
+            "rccl": rccl,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": s_achieved / HBM_PEAK_GBS,
                          "traffic": traffic_j.get("k_trace_bytes_per_launch"), "traffic_source": traffic_j.get("source"),
                          "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": s_bytes,
-                         "basis": "un-overlapped launches: %d frames on one renderer with nothing co-running, HIP events on its stream around every k_trace launch — "
-                                  "the duration rocprofv3's kernel trace reports for the same launches (profiles/, *_solo_kernel_stats.csv)" % SOLO_FRAMES,
-                         "overlapped": {"achieved": o_achieved, "frac": o_achieved / HBM_PEAK_GBS, "avg_launch_ms": o_avg, "launches": o_launches, "bytes_per_launch": o_bytes,
-                                        "frames_in_flight": P,
-                                        "note": "the timed region: HIP events around every k_trace launch while %d frames share the chip; a launch then also counts the time it "
-                                                "waits for, or shares, the CUs — a scheduling figure, not a kernel figure" % P},
+                         "basis": "the timed region itself: one frame at a time on one renderer, HIP events on the stream the kernel runs on around every k_trace launch — "
+                                  "the duration rocprofv3's kernel trace reports for the same command (profiles/)",
                          "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
-                                    "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation): a lower bound"},
+                                    "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation, the read-back): a lower bound"},
                          "limits": limits_j,
                          "binding_limit": ({"name": "valu_issue", "frac": limits_j["valu_issue"]["frac"], "source": limits_j.get("source"),
-                                            "note": "the kernel's algorithmic bytes come from L2 / Infinity Cache (traffic is 0.31 of the HBM roof): what binds it is the VALU issue "
-                                                    "rate of its instruction mix (PMC pass, tools/limits_from_pmc.py), not the HBM roof `frac` is quoted against"}
+                                            "note": "the kernel's algorithmic bytes come from L2 / Infinity Cache: what binds it is the VALU issue rate of its instruction mix and its "
+                                                    "lane efficiency (PMC pass, tools/limits_from_pmc.py), not the HBM roof `frac` is quoted against"}
                                            if limits_j and "valu_issue" in limits_j else None),
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
             "stage_ms_per_frame": {k: v[0] / n_frames for k, v in timings.items()},
-            "stage_ms_per_frame_solo": {k: v[0] / SOLO_FRAMES for k, v in solo_t.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(desc, view, effective_cpus())
+            out["cpu_baseline"] = cpu_baseline(desc, view, effective_cpus(), T)
         elif world > 1:
             out["cpu_baseline"] = None
-    else:
-        out = None
     if use_dist:
         dist.barrier()
-    for rr in rs:
-        rr.close()
-    if comm is not None:
-        comm.close()
+    for c in comms:
+        c.close()
     if use_dist:
         dist.destroy_process_group()
     probe.close()
@@ -423,7 +568,21 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)       # parent: never touches a GPU
+    if args.spawn_dry_run:
+        if "WORLD_SIZE" not in os.environ:
+            os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port())})
+        return dry_run(args)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -30,6 +30,7 @@ int main(int argc, char **argv) {
     const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 1280, height = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 720;
     const int frames = argc > 5 ? std::atoi(argv[5]) : 16;
     const uint32_t bounces = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 3;  // reference constant (renderer.rs:398-399)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // one hardware queue per HIP stream; the host's decision, before the first HIP call
     try {
         Device device(0);
         Scene scene;                                       // Scene::default()

@@ -143,6 +143,8 @@ class Renderer {  // renderer.rs:169-811
         check(lpt_renderer_set_accumulate(h_, accumulate ? 1 : 0));
         check(lpt_renderer_raytrace(h_, view_transform.data()));
     }
+    /// queue.submit(encoder.finish()) (app.rs:335-337): launches what raytrace() has recorded; asynchronous
+    void submit() { check(lpt_renderer_submit(h_)); }
     void reset_accumulation() { accumulate = false; check(lpt_renderer_reset_accumulation(h_)); }
     void upload_noise_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, uint32_t bytes_per_row) { check(lpt_renderer_upload_noise(h_, rgba8, w, h, bytes_per_row)); }
     void use_noise_texture(bool flag) { check(lpt_renderer_use_noise(h_, flag ? 1 : 0)); }

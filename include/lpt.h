@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LPT_ABI_VERSION 2u
+#define LPT_ABI_VERSION 3u
 
 /* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
 #define LPT_INVALID_INDEX 0xFFFFFFFFu
@@ -316,11 +316,25 @@ uint32_t lpt_max_per_pixel_bytes(void);
 int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg,
                                const lpt_probe *probe_or_null);
 /* replaces: Renderer::raytrace(&mut encoder,&queue,&Mat4) (renderer.rs:392-549).
- * Enqueues ONE sample per pixel on the renderer's stream and returns without
- * waiting ("record now, submit later").  `view_transform` is camera-to-world
- * (crates/standalone/src/camera.rs:101-108).  Returns LPT_OK and does nothing
- * when resources are unset (renderer.rs:403-407,419-422). */
+ * RECORDS one sample per pixel and returns: like the reference, which records the passes of a frame into a command
+ * encoder that the app submits once (crates/standalone/src/app.rs:335-337), the launches happen at the next SUBMISSION
+ * POINT — lpt_renderer_submit, every call that reads or waits (read_*, blit, exchange, synchronize, get_ray_counts,
+ * get_timings, ...) and every setter whose value the passes read (resize, set_resources, set_blit_mode, set_shard, ...).
+ * The protocol state of the reference (frame_count, seed, the frame_back toggle) moves at record time.  Consecutive
+ * recorded calls with the same view that continue one accumulation are submitted as ONE wavefront of n samples per
+ * pixel (bit for bit the result of n separate launches: lpt_renderer_raytrace_n's contract), which is what keeps the
+ * persistent traversal waves fed when the caller issues its samples one call at a time.  `view_transform` is
+ * camera-to-world (crates/standalone/src/camera.rs:101-108).  Returns LPT_OK and does nothing when resources are unset
+ * (renderer.rs:403-407,419-422).  The denoising BlitModes (one temporal pass per call) submit at once.  An error of a
+ * deferred launch (e.g. out of device memory) is reported by the call that submits it. */
 int lpt_renderer_raytrace(lpt_renderer *r, const float view_transform[16]);
+/* replaces: queue.submit(Some(encoder.finish())) (crates/standalone/src/app.rs:335-337): launches what has been recorded.
+ * Asynchronous (nothing waits for the GPU); a no-op when nothing is pending. */
+int lpt_renderer_submit(lpt_renderer *r);
+/* new (no reference knob): the largest number of recorded calls one submission fuses.  0 = automatic (about 16 M rays per
+ * wavefront: 8 samples at 1920x1080, 2 at 3840x2160; a full batch is submitted at once), 1 = every raytrace() launches
+ * immediately (the round-2 behaviour), up to 64.  Costs ray-queue memory: 176 B per ray in flight and wavefront lane. */
+int lpt_renderer_set_max_fused(lpt_renderer *r, uint32_t n);
 /* Build-only batching of the call above: exactly equivalent (bit for bit) to
  * n x { lpt_renderer_raytrace(r, view); accumulate = true (app.rs:318); } but traced as ONE wavefront
  * of n samples per pixel (sample-major queues), which keeps the persistent traversal waves fed.
@@ -352,8 +366,13 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes);
  * Blocking (the reference's device.poll(Wait), :791); w*h*4 bytes, tight rows. */
 int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst);
 /* Parity surface (no reference twin): mean radiance, w*h*4 floats, a = 1 where
- * this process owns the pixel and has accumulated at least one sample. */
+ * this process owns the pixel and has accumulated at least one sample.  Blocking.  `dst` may be pageable memory (the
+ * HIP runtime stages the copy: 27 GB/s measured) or memory from lpt_host_alloc (one DMA at link speed). */
 int lpt_renderer_read_radiance(lpt_renderer *r, float *dst);
+/* new: page-locked host memory for read-back destinations (the wgpu staging buffer the reference maps in read_pixels,
+ * renderer.rs:772-800, is such memory too).  Any lpt_device must exist first.  Free with lpt_host_free. */
+int lpt_host_alloc(size_t bytes, void **out);
+int lpt_host_free(void *ptr);
 /* replaces: renderer.queries.values()/labels()
  * (crates/standalone/src/gui/windows/performance_info.rs:19-20) */
 int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count);
@@ -406,8 +425,11 @@ int lpt_comm_unique_id(void *out_id /* LPT_COMM_ID_BYTES */);
 int lpt_comm_create(lpt_device *dev, const void *id /* LPT_COMM_ID_BYTES */, int rank, int world_size, lpt_comm **out);
 /* Unbind every renderer first (lpt_renderer_set_comm(r, NULL) or destroy it). */
 int lpt_comm_destroy(lpt_comm *comm);
+/* rank and size as RCCL reports them for the communicator (ncclCommUserRank / ncclCommCount) */
 int lpt_comm_info(const lpt_comm *comm, int *rank, int *world_size);
-/* ncclGroupStart / ncclGroupEnd: needed only when ONE thread drives several communicators (right column above). */
+/* ncclGroupStart / ncclGroupEnd: needed only when ONE thread drives several communicators (right column above).
+ * lpt_renderer_exchange inside such a bracket enqueues its pack + send / recv / reduce only; RCCL issues them at the
+ * outermost end, and lpt_comm_group_end then enqueues what consumes the received data (unpack, filter passes). */
 int lpt_comm_group_begin(void);
 int lpt_comm_group_end(void);
 

@@ -111,6 +111,10 @@ SIGNATURES = {
     "lpt_renderer_set_resources": (_i, [_vp, _vp, _vp]),
     "lpt_renderer_raytrace": (_i, [_vp, _vp]),
     "lpt_renderer_raytrace_n": (_i, [_vp, _vp, _u32]),
+    "lpt_renderer_submit": (_i, [_vp]),
+    "lpt_renderer_set_max_fused": (_i, [_vp, _u32]),
+    "lpt_host_alloc": (_i, [_sz, _pvp]),
+    "lpt_host_free": (_i, [_vp]),
     "lpt_renderer_reset_accumulation": (_i, [_vp]),
     "lpt_renderer_set_accumulate": (_i, [_vp, _i]),
     "lpt_renderer_get_accumulate": (_i, [_vp, C.POINTER(_i)]),

@@ -341,6 +341,14 @@ class Renderer:
         m = np.ascontiguousarray(view_transform, np.float32).reshape(16)
         _check(A.lib().lpt_renderer_raytrace_n(self._h, A.ptr(m), int(n_samples)))
 
+    def submit(self):
+        """queue.submit(encoder.finish()) (app.rs:335-337): launch what raytrace() has recorded; asynchronous"""
+        _check(A.lib().lpt_renderer_submit(self._h))
+
+    def set_max_fused(self, n):
+        """recorded raytrace() calls one submission may fuse into a wavefront: 0 = automatic, 1 = every call launches at once"""
+        _check(A.lib().lpt_renderer_set_max_fused(self._h, int(n)))
+
     def reset_accumulation(self):
         _check(A.lib().lpt_renderer_reset_accumulation(self._h))
 
@@ -367,9 +375,14 @@ class Renderer:
         return out
 
     # ---- build-only extensions
-    def read_radiance(self):
+    def read_radiance(self, out=None):
+        """mean radiance (h, w, 4) float32.  `out`: a destination to fill instead of a fresh array — e.g. a `pinned_array`
+        (page-locked: one DMA at link speed instead of the runtime's staged copy into pageable memory)"""
         w, h = self.get_size()
-        out = np.zeros((h, w, 4), np.float32)
+        if out is None:
+            out = np.empty((h, w, 4), np.float32)
+        elif out.shape != (h, w, 4) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("read_radiance: out must be a C-contiguous float32 array of shape (%d, %d, 4)" % (h, w))
         _check(A.lib().lpt_renderer_read_radiance(self._h, A.ptr(out)))
         return out
 
@@ -473,6 +486,34 @@ class Renderer:
         if self._h:
             A.lib().lpt_renderer_destroy(self._h)
             self._h = None
+
+
+class _PinnedBlock:
+    """owner of one lpt_host_alloc block (freed when the last array viewing it dies)"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(A.lib().lpt_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                A.lib().lpt_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_array(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (lpt_host_alloc): a read-back destination the GPU writes with one DMA.
+    A Device must exist."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    block = _PinnedBlock(max(n, 1))
+    buf = (C.c_char * max(n, 1)).from_address(block.ptr)
+    buf._lpt_owner = block   # keeps the block alive as long as the ctypes buffer (and any array over it) lives
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class loaders:

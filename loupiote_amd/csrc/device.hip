@@ -9,8 +9,12 @@
 // Also here: the multi-GPU frame exchange (plain RCCL: lpt_comm_*, lpt_renderer_exchange).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 
 #include "common.h"
@@ -33,6 +37,7 @@ struct lpt_device {
     hipStream_t stream = nullptr;
     int compute_units = 0;
     char name[128] = {0};
+    std::vector<lpt_renderer *> renderers;   // live renderers of this device: scene / probe edits submit their recorded calls first
 };
 
 // one RCCL communicator rank (frame exchange); created by lpt_comm_create
@@ -42,10 +47,58 @@ struct lpt_comm {
     int rank = 0, world = 1;
 };
 
+// librccl is opened on the first lpt_comm_* call, not at load time: a single-GPU host never needs it (and never pays for
+// loading it).  rccl.h supplies the types only; nothing here links against the library.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+// nullptr (and lpt_last_error set) when librccl cannot be opened
+static const Rccl *rccl() {
+    static Rccl table;
+    static int state = 0;   // 0 = not tried, 1 = loaded, -1 = failed
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state == 1) return &table;
+    if (state == 0) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        std::string rocm_path;
+        if (const char *rp = getenv("ROCM_PATH")) rocm_path = std::string(rp) + "/lib/librccl.so";
+        void *h = nullptr;
+        if (!rocm_path.empty()) h = dlopen(rocm_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        for (size_t i = 0; !h && i < sizeof names / sizeof names[0]; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        state = -1;
+        if (h) {
+            table.handle = h;
+            bool ok = true;
+#define RCCL_SYM(field, sym) do { *(void **)(&table.field) = dlsym(h, sym); if (!table.field) ok = false; } while (0)
+            RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RCCL_SYM(CommInitRank, "ncclCommInitRank"); RCCL_SYM(CommDestroy, "ncclCommDestroy");
+            RCCL_SYM(CommCount, "ncclCommCount"); RCCL_SYM(CommUserRank, "ncclCommUserRank");
+            RCCL_SYM(GroupStart, "ncclGroupStart"); RCCL_SYM(GroupEnd, "ncclGroupEnd"); RCCL_SYM(Send, "ncclSend"); RCCL_SYM(Recv, "ncclRecv");
+            RCCL_SYM(Reduce, "ncclReduce"); RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+            if (ok) state = 1;
+        }
+    }
+    if (state == 1) return &table;
+    fail(LPT_ERR_RCCL, "librccl could not be loaded (%s): the multi-GPU frame exchange needs RCCL", dlerror() ? dlerror() : "missing symbol");
+    return nullptr;
+}
+
 #define RCCL_TRY(expr)                                                                                \
     do {                                                                                              \
         ncclResult_t r__ = (expr);                                                                    \
-        if (r__ != ncclSuccess) return fail(LPT_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r__)); \
+        if (r__ != ncclSuccess) return fail(LPT_ERR_RCCL, "%s failed: %s", #expr, rccl() ? rccl()->GetErrorString(r__) : "?"); \
     } while (0)
 
 struct lpt_scene_gpu {
@@ -70,8 +123,8 @@ struct lpt_probe {
     void *rgbe = nullptr;
 };
 
-enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_COUNT };
-static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf"};
+enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_EXCHANGE, ST_COUNT };
+static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange"};
 
 // One independent wavefront context ("lane") of a renderer: everything a raytrace() call owns while its rays are in flight.
 // Consecutive raytrace() calls of ONE renderer take the lanes in turn (default 2), so the traversal / shading of call k+1
@@ -107,6 +160,12 @@ struct lpt_renderer {
     // global_uniforms (renderer.rs:286-290)
     uint32_t frame_count = 1, seed = 0;
     bool accumulate = false, frame_back = true;
+    // Recorded, not yet submitted raytrace() calls ("record now, submit later": the reference records every pass of a frame
+    // into one encoder, renderer.rs:392-549, and the app submits it once, app.rs:335-337).  Consecutive calls with the same
+    // view that continue one accumulation fuse into ONE wavefront of `n` samples per pixel; the host-side protocol state
+    // (frame_count, seed, frame_back) moves at record time, the snapshot below is what the launches use.
+    struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
+    uint32_t max_fused = 0;    // samples one submission may fuse; 0 = auto (about 16 M rays per wavefront), 1 = every call launches at once
     int mode = LPT_BLIT_PATHTRACE;
     // build-only knobs
     uint32_t max_bounces = 3, user_seed = 0;
@@ -121,8 +180,6 @@ struct lpt_renderer {
     uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
-    uint32_t *n_slots_host = nullptr;  // pinned ring of dense ray counts (source of the async qcount[0] preset)
-    uint32_t n_slots_ring = 0;
     float4 *accum = nullptr, *scratch = nullptr;
     // frame exchange (lpt_renderer_exchange): `frame` = the presented whole frame on rank 0 (accum stays owned-only),
     // `xstage` = packed owned tiles (this rank's; on rank 0 those of every rank, concatenated)
@@ -162,6 +219,14 @@ struct lpt_renderer {
 };
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+// submits the recorded raytrace() calls; every synchronisation point, and every setter whose value the launches read, runs it first
+static int flush_pending(lpt_renderer *r);
+#define FLUSH_OR_RETURN(r) do { int fst__ = flush_pending(r); if (fst__ != LPT_OK) return fst__; } while (0)
+// Recorded raytrace() calls saw the scene / probe as it was when they were issued: an edit (or a destroy) submits them first.
+static void flush_device(lpt_device *dev) {
+    if (!dev) return;
+    for (lpt_renderer *r : dev->renderers) flush_pending(r);
+}
 // what read_radiance / read_pixels / blit show: the exchanged whole frame after lpt_renderer_exchange, else the local target
 static inline const float4 *presented_target(const lpt_renderer *r) { return (r->presented && r->frame) ? r->frame : r->accum; }
 static inline size_t stack_bytes(const DScene &sc) { return (size_t)sc.stack_entries * kTraceBlock * sizeof(uint2); }
@@ -324,11 +389,10 @@ extern "C" {
 // ============================================================================ Device
 int lpt_device_create(int hip_ordinal, lpt_device **out) {
     if (!out) return fail(LPT_ERR_INVALID_ARG, "lpt_device_create: null out");
-    // A renderer spreads its work over several HIP streams (wavefront lanes, several renderers in flight); the ROCm runtime
-    // maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, of which these streams get two) and streams that share a
-    // queue serialise.  Ask for 8 unless the host chose a value; it only takes effect if the HIP runtime has not been
-    // initialised by someone else yet.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // A renderer spreads its work over several HIP streams (wavefront lanes, several renderers in flight).  The ROCm runtime
+    // maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise: a host that
+    // keeps more than two frames in flight sets GPU_MAX_HW_QUEUES=8 in its environment BEFORE its first HIP call
+    // (INTEGRATION.md §8).  The library does not touch the process environment.
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -380,6 +444,7 @@ int lpt_device_stream(lpt_device *dev, void **stream) {
 int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     if (!sg) return LPT_OK;
     hipSetDevice(sg->dev->ordinal);
+    flush_device(sg->dev);
     hipDeviceSynchronize();   // renderers trace on their own streams: frames still in flight read what is freed here
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
                     sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena};
@@ -566,6 +631,7 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
     hipStream_t s = sg->dev->stream;
     // renderers trace on their own streams and raytrace() is asynchronous: frames still in flight read the triangles and
     // nodes this call rewrites in place, so wait for every stream of the device first
+    flush_device(sg->dev);
     HIP_TRY(hipDeviceSynchronize());
     uint32_t changed = 0;
     for (size_t i = 0; i < scene->instances.size(); ++i) {
@@ -619,6 +685,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
     if (n < 16u) return lpt_scene_gpu_update_instances(sg, scene, nullptr);
     HIP_TRY(hipSetDevice(sg->dev->ordinal));
     hipStream_t s = sg->dev->stream;
+    flush_device(sg->dev);
     HIP_TRY(hipDeviceSynchronize());  // frames in flight on the renderers' streams still read what is rebuilt here
     void *woop_prim = nullptr;
     HIP_TRY(hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)n));
@@ -690,6 +757,7 @@ int lpt_probe_upload(lpt_device *dev, const uint8_t *rgbe8, uint32_t w, uint32_t
 int lpt_probe_destroy(lpt_probe *p) {
     if (!p) return LPT_OK;
     hipSetDevice(p->dev->ordinal);
+    flush_device(p->dev);
     hipDeviceSynchronize();   // frames in flight on the renderers' streams may still sample the probe
     if (p->rgbe) hipFree(p->rgbe);
     delete p;
@@ -890,7 +958,6 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     if (const char *ev = getenv("LPT_LANES")) r->n_lanes = std::max(1, std::min(kMaxLanes, atoi(ev)));
     hipError_t e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&r->n_slots_host, 64 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
     if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
     if (e == hipSuccess) e = hipMalloc(&r->srgb_thr, 256 * sizeof(float));
@@ -910,6 +977,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     }
     int st = alloc_frame_buffers(r);
     if (st != LPT_OK) { lpt_renderer_destroy(r); return st; }
+    dev->renderers.push_back(r);
     *out = r;
     return LPT_OK;
 }
@@ -917,6 +985,11 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
 int lpt_renderer_destroy(lpt_renderer *r) {
     if (!r) return LPT_OK;
     hipSetDevice(r->dev->ordinal);
+    r->pend.n = 0;   // recorded but never submitted: nobody can read the result any more
+    {
+        auto &v = r->dev->renderers;
+        v.erase(std::remove(v.begin(), v.end(), r), v.end());
+    }
     hipStreamSynchronize(r->stream);
     free_frame_buffers(r);
     for (int l = 0; l < kMaxLanes; ++l) {
@@ -929,7 +1002,6 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     if (r->totals) hipFree(r->totals);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->srgb_thr) hipFree(r->srgb_thr);
-    if (r->n_slots_host) hipHostFree(r->n_slots_host);
     if (r->xevent) hipEventDestroy(r->xevent);
     if (r->stream) hipStreamDestroy(r->stream);
     if (r->noise) hipFree(r->noise);
@@ -944,6 +1016,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
 
 int lpt_renderer_set_downsample(lpt_renderer *r, float factor) {
     if (!r || !(factor > 0.f) || factor > 16.f) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_downsample: factor must be in (0,16]");
+    FLUSH_OR_RETURN(r);
     r->downsample = factor;
     return LPT_OK;
 }
@@ -951,6 +1024,7 @@ int lpt_renderer_set_downsample(lpt_renderer *r, float factor) {
 int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe) {
     if (!r || !sg) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_resources: null");
     if (sg->dev != r->dev || (probe && probe->dev != r->dev)) return fail(LPT_ERR_INVALID_ARG, "resources belong to another device");
+    FLUSH_OR_RETURN(r);
     r->sg = sg;
     r->probe = probe;
     r->resources_set = true;
@@ -960,6 +1034,7 @@ int lpt_renderer_set_resources(lpt_renderer *r, const lpt_scene_gpu *sg, const l
 
 int lpt_renderer_resize(lpt_renderer *r, const lpt_scene_gpu *sg, const lpt_probe *probe, uint32_t width, uint32_t height) {
     if (!r || !sg) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_resize: null");
+    FLUSH_OR_RETURN(r);
     const uint32_t nw = (uint32_t)((float)width * r->downsample), nh = (uint32_t)((float)height * r->downsample);
     if (nw > 8192u || nh > 8192u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_resize: the path-traced size is limited to 8192 x 8192 (got %u x %u)", nw, nh);
     r->req_w = width; r->req_h = height;
@@ -982,22 +1057,26 @@ uint32_t lpt_max_per_pixel_bytes(void) { return 48u; }
 
 int lpt_renderer_set_max_bounces(lpt_renderer *r, uint32_t b) {
     if (!r || b == 0 || b > (uint32_t)kMaxBounces) return fail(LPT_ERR_INVALID_ARG, "max_bounces must be in [1,%d]", kMaxBounces);
+    FLUSH_OR_RETURN(r);
     r->max_bounces = b;
     return LPT_OK;
 }
 int lpt_renderer_set_seed(lpt_renderer *r, uint32_t s) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_seed: null");
+    FLUSH_OR_RETURN(r);
     r->user_seed = s;
     return LPT_OK;
 }
 int lpt_renderer_set_vfov(lpt_renderer *r, float radians) {
     if (!r || !(radians > 0.f) || !(radians < 3.14159f)) return fail(LPT_ERR_INVALID_ARG, "vfov must be in (0, pi)");
+    FLUSH_OR_RETURN(r);
     r->vfov = radians;
     return LPT_OK;
 }
 int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h) {
     if (!r || world == 0 || rank >= world || tile_w == 0 || tile_h == 0 || (tile_w * tile_h) % 64u != 0u)
         return fail(LPT_ERR_INVALID_ARG, "bad shard (rank %u of %u, tile %ux%u; tile area must be a multiple of 64)", rank, world, tile_w, tile_h);
+    FLUSH_OR_RETURN(r);
     r->rank = rank; r->world = world; r->tile_w = tile_w; r->tile_h = tile_h;
     r->frame_count = 1;
     return alloc_frame_buffers(r);
@@ -1026,6 +1105,7 @@ int lpt_renderer_get_frame_state(const lpt_renderer *r, uint32_t *fc, uint32_t *
 }
 int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t w, uint32_t h, uint32_t row_bytes) {
     if (!r || !rgba8 || !w || !h || row_bytes < w * 4u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_upload_noise: bad arguments");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->noise) { hipFree(r->noise); r->noise = nullptr; }
@@ -1036,16 +1116,19 @@ int lpt_renderer_upload_noise(lpt_renderer *r, const uint8_t *rgba8, uint32_t w,
 }
 int lpt_renderer_use_noise(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_use_noise: null");
+    FLUSH_OR_RETURN(r);
     r->use_noise = flag != 0;
     return LPT_OK;
 }
 int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode) {
     if (!r || mode < LPT_BLIT_PATHTRACE || mode > LPT_BLIT_MOTION) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_blit_mode: bad mode %d", mode);
+    FLUSH_OR_RETURN(r);
     r->mode = mode;
     return LPT_OK;
 }
 int lpt_renderer_set_lanes(lpt_renderer *r, int lanes) {
     if (!r || lanes < 1 || lanes > kMaxLanes) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_lanes: 1..%d", kMaxLanes);
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));   // behind its waits: every lane's work
     for (int l = 0; l < kMaxLanes; ++l) {
@@ -1059,16 +1142,19 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes) {
 }
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_sort_queues: null");
+    FLUSH_OR_RETURN(r);
     r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;   // 1: next-bounce queue, 2: shadow queue, 3 (or any other non-zero): both
     return LPT_OK;
 }
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_stats: null");
+    FLUSH_OR_RETURN(r);
     r->stats = flag != 0;
     return LPT_OK;
 }
 int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_timings: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     const int total = lpt_renderer::kRing * lpt_renderer::kMaxEvents;
     if (flag && !r->ev_start) {
@@ -1115,8 +1201,6 @@ static inline void stage_end(lpt_renderer *r, hipStream_t stream) {
     r->ev_count[slot]++;
 }
 
-int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) { return lpt_renderer_raytrace_n(r, view, 1u); }
-
 }  // extern "C"
 
 // asvgf.render (renderer.rs:513-518, asvgf.rs:250-291) / asvgf.temporal_pass (:519-522) over the whole frame, from the
@@ -1144,24 +1228,11 @@ static void launch_filter(lpt_renderer *r, hipStream_t s) {
 
 extern "C" {
 
-int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_samples) {
-    if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
-    if (n_samples == 0u || n_samples > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace_n: n must be in [1,64]");
-    if (r->mode != LPT_BLIT_PATHTRACE && n_samples > 1u) {
-        // the denoiser consumes one sample per frame (temporal pass per raytrace): no batching
-        for (uint32_t k = 0; k < n_samples; ++k) {
-            int st = lpt_renderer_raytrace_n(r, view, 1u);
-            if (st != LPT_OK) return st;
-            r->accumulate = true;
-        }
-        return LPT_OK;
-    }
-    if (n_samples & 1u) r->frame_back = !r->frame_back;   // renderer.rs:401, once per emulated call
-    if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
-    if (!r->w || !r->h) return LPT_OK;
+// The launches of `n_samples` recorded raytrace() calls as ONE wavefront, from the protocol state the first of them saw
+// (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with accumulate == true by construction).
+static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     hipStream_t sm = r->stream;                  // accumulation, filter passes, bookkeeping, reads, the exchange: in call order
-    r->presented = false;                        // a new sample: the exchanged frame (if any) is stale
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
 
     FrameParams p;
@@ -1174,13 +1245,13 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
     p.ax = aspect * th; p.ay = th;
     p.width = r->w; p.height = r->h;             // camera.dimensions / global_uniforms.dimensions (:431,436)
     p.user_seed = r->user_seed;
-    p.seed_counter = r->seed;
+    p.seed_counter = seed0;
     p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
-    p.frame_count = r->frame_count;
+    p.frame_count = frame_count0;
     p.max_bounces = nb;
     p.n_samples = n_samples;
-    p.fc_inc0 = r->accumulate ? 1u : 0u;
+    p.fc_inc0 = acc0 ? 1u : 0u;
     const uint32_t n_rays = p.n_slots * n_samples;
     const bool denoise = r->mode != LPT_BLIT_PATHTRACE;
     // the lane (Wavefront) this call's rays live in: consecutive calls take the lanes in turn; the denoising modes
@@ -1247,16 +1318,13 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         stage_begin(r, ST_RAYGEN, s);
         const bool dense = (r->w % r->tile_w == 0u) && (r->h % r->tile_h == 0u);
         if (dense) {
-            uint32_t *src = r->n_slots_host + (r->n_slots_ring++ & 63u);  // pinned; stays valid until the copy has run
-            *src = n_rays;
-            HIP_TRY(hipMemcpyAsync(&wf.ctr->qcount[0], src, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_raygen<true>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, wf.q[0], wf.Lsum, wf.ctr);
         } else {
             hipLaunchKernelGGL(k_raygen<false>, dim3(stream_blocks), dim3(kBlock), 0, s, p, nz, wf.q[0], wf.Lsum, wf.ctr);
         }
         stage_end(r, s);
 
-        uint32_t seed = r->seed;
+        uint32_t seed = seed0;
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
         // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
         // instead of 2*nb; split (LPT_MERGE_TRACE=0): IntersectorPass and the shadow pass as separate launches.
@@ -1318,25 +1386,96 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         }
         HIP_TRY(hipGetLastError());
     }
-    // bookkeeping of n emulated calls: { raytrace(); accumulate = true (app.rs:318); } x n
-    r->seed += nb * n_samples;                   // seed += 1 per intersect stage, never reset
-    if (r->mode == LPT_BLIT_PATHTRACE) {         // frame_count only moves in the Pahtrace arm (:523-538)
-        if (r->accumulate) r->frame_count += 1u; // :535-537 for the first call
-        r->frame_count += n_samples - 1u;        // later calls run with accumulate == true
-    }
     if (denoise) r->prev_cam = gb.cur;           // prev_model_to_screen = P * V^-1 (:542-546)
-    if (n_samples > 1u) r->accumulate = true;
     return LPT_OK;
+}
+
+// submit what has been recorded (every synchronisation point and every setter that the launches read calls this first)
+static int flush_pending(lpt_renderer *r) {
+    if (!r->pend.n) return LPT_OK;
+    const lpt_renderer::Pending b = r->pend;
+    r->pend.n = 0;
+    return submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0);
+}
+
+static uint32_t fuse_cap(const lpt_renderer *r) {
+    if (r->max_fused) return r->max_fused;
+    uint32_t tiles_x, n_tiles, n_slots;
+    shard_geometry(r, tiles_x, n_tiles, n_slots);
+    return std::max(1u, std::min(64u, (1u << 24) / std::max(n_slots, 1u)));   // about 16 M rays (2.8 GB of ray state) per wavefront
+}
+
+// Records ONE raytrace() call: the host-side protocol of Renderer::raytrace moves now (frame_back :401, seed :453/:487,
+// frame_count :535-537), the launches wait for the next submission point.  A call fuses with the recorded ones when it
+// continues the same accumulation from the same view — then the n calls are bit for bit the n samples of one wavefront
+// (lpt_renderer_raytrace_n's contract; tests/test_gpu_deferred.py).
+static int record_call(lpt_renderer *r, const float view[16]) {
+    r->frame_back = !r->frame_back;              // renderer.rs:401
+    if (!r->resources_set || !r->sg) return LPT_OK;  // :403-407, :419-422
+    if (!r->w || !r->h) return LPT_OK;
+    r->presented = false;                        // a new sample: the exchanged frame (if any) is stale
+    lpt_renderer::Pending &b = r->pend;
+    const bool pathtrace = r->mode == LPT_BLIT_PATHTRACE;
+    if (b.n) {
+        const uint32_t expect_fc = b.frame_count0 + (b.acc0 ? 1u : 0u) + (b.n - 1u);
+        const bool fuses = pathtrace && r->accumulate && r->frame_count == expect_fc && b.n < fuse_cap(r) && memcmp(view, b.view, sizeof b.view) == 0;
+        if (!fuses) FLUSH_OR_RETURN(r);
+    }
+    if (!b.n) {
+        memcpy(b.view, view, sizeof b.view);
+        b.frame_count0 = r->frame_count; b.seed0 = r->seed; b.acc0 = r->accumulate;
+    }
+    b.n++;
+    r->seed += r->max_bounces;                   // seed += 1 per intersect stage, never reset
+    if (pathtrace && r->accumulate) r->frame_count += 1u;   // frame_count only moves in the Pathtrace arm (:523-538)
+    // the denoising modes carry frame-to-frame state (one temporal pass per call): they launch at once; so does a full batch
+    if (!pathtrace || b.n >= fuse_cap(r)) return flush_pending(r);
+    return LPT_OK;
+}
+
+int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
+    if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
+    return record_call(r, view);
+}
+
+int lpt_renderer_submit(lpt_renderer *r) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_submit: null");
+    return flush_pending(r);
+}
+
+int lpt_renderer_set_max_fused(lpt_renderer *r, uint32_t n) {
+    if (!r || n > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_max_fused: 0 (auto) or 1..64");
+    FLUSH_OR_RETURN(r);
+    r->max_fused = n;
+    return LPT_OK;
+}
+
+int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_samples) {
+    if (!r || !view) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace: null");
+    if (n_samples == 0u || n_samples > 64u) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_raytrace_n: n must be in [1,64]");
+    // n x { raytrace(view); accumulate = true (app.rs:318); }, submitted at once: the explicit batched form
+    const uint32_t keep = r->max_fused;
+    if (r->mode == LPT_BLIT_PATHTRACE) r->max_fused = std::min(64u, std::max(fuse_cap(r), n_samples + r->pend.n));   // the caller asked for this batch size
+    int st = LPT_OK;
+    for (uint32_t k = 0; k < n_samples && st == LPT_OK; ++k) {
+        st = record_call(r, view);
+        if (n_samples > 1u) r->accumulate = true;
+    }
+    r->max_fused = keep;
+    if (st == LPT_OK) st = flush_pending(r);
+    return st;
 }
 
 int lpt_renderer_stream(lpt_renderer *r, void **stream) {
     if (!r || !stream) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_stream: null");
+    FLUSH_OR_RETURN(r);
     *stream = (void *)r->stream;
     return LPT_OK;
 }
 
 int lpt_renderer_synchronize(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_synchronize: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return LPT_OK;
@@ -1344,6 +1483,7 @@ int lpt_renderer_synchronize(lpt_renderer *r) {
 
 int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes) {
     if (!r || !ptr) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_radiance_device_ptr: null");
+    FLUSH_OR_RETURN(r);
     *ptr = r->accum;
     if (bytes) *bytes = sizeof(float4) * (size_t)r->w * r->h;
     return LPT_OK;
@@ -1351,6 +1491,7 @@ int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes)
 
 int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (!r || !dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance: null");
+    FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);
     const uint32_t n = r->w * r->h;
@@ -1361,8 +1502,19 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     return LPT_OK;
 }
 
+int lpt_host_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return fail(LPT_ERR_INVALID_ARG, "lpt_host_alloc: null / zero size");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return LPT_OK;
+}
+int lpt_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return LPT_OK;
+}
+
 int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
     if (!r || !dst || row_bytes < (size_t)r->w * 4) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_blit_rgba8: bad arguments");
+    FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);
     const uint32_t n = r->w * r->h;
@@ -1391,6 +1543,7 @@ int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst) {
 
 int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion, float *radiance, uint32_t *history) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_denoiser: null");
+    FLUSH_OR_RETURN(r);
     if (!r->den_temp) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no denoising frame has been traced");
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1409,6 +1562,7 @@ int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion
 // calls lpt_renderer_denoise_filter there, which runs the temporal / a-trous / composite passes over the whole frame.
 int lpt_renderer_denoiser_inputs(lpt_renderer *r, void **noisy, void **gbuffer, void **motion, size_t *n_pixels) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoiser_inputs: null");
+    FLUSH_OR_RETURN(r);
     if (!r->den_temp) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoiser_inputs: no denoising frame has been traced");
     if (noisy) *noisy = r->den_noisy;
     if (gbuffer) *gbuffer = r->den_gbuf[r->den_cur];
@@ -1419,6 +1573,7 @@ int lpt_renderer_denoiser_inputs(lpt_renderer *r, void **noisy, void **gbuffer, 
 
 int lpt_renderer_denoise_filter(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoise_filter: null");
+    FLUSH_OR_RETURN(r);
     if (!r->den_temp || !r->den_inputs_ready) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_denoise_filter: no denoising frame has been traced");
     if (r->world == 1u) return LPT_OK;  // raytrace() has already filtered the frame
     HIP_TRY(hipSetDevice(r->dev->ordinal));
@@ -1430,6 +1585,7 @@ int lpt_renderer_denoise_filter(lpt_renderer *r) {
 
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     if (!r || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_ray_counts: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     Totals t;
     HIP_TRY(hipMemcpyAsync(&t, r->totals, sizeof t, hipMemcpyDeviceToHost, r->stream));
@@ -1442,6 +1598,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
 
 int lpt_renderer_reset_ray_counts(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_reset_ray_counts: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipMemsetAsync(r->totals, 0, sizeof(Totals), r->stream));
     return LPT_OK;
@@ -1449,6 +1606,7 @@ int lpt_renderer_reset_ray_counts(lpt_renderer *r) {
 
 int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count) {
     if (!r || !inout_count) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_timings: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));
     lpt_timing acc[ST_COUNT];
@@ -1467,6 +1625,7 @@ int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count)
 
 int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *shadow, uint32_t cap) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_queue_counts: null");
+    FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     const uint32_t n = std::min<uint32_t>(cap, (uint32_t)kMaxBounces);
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1481,8 +1640,10 @@ int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *
 int lpt_comm_unique_id(void *out_id) {
     if (!out_id) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_unique_id: null");
     static_assert(sizeof(ncclUniqueId) == LPT_COMM_ID_BYTES, "LPT_COMM_ID_BYTES must match ncclUniqueId");
+    const Rccl *nc = rccl();
+    if (!nc) return LPT_ERR_RCCL;
     ncclUniqueId id;
-    RCCL_TRY(ncclGetUniqueId(&id));
+    RCCL_TRY(nc->GetUniqueId(&id));
     memcpy(out_id, &id, sizeof id);
     return LPT_OK;
 }
@@ -1490,14 +1651,16 @@ int lpt_comm_unique_id(void *out_id) {
 int lpt_comm_create(lpt_device *dev, const void *id_bytes, int rank, int world, lpt_comm **out) {
     if (!dev || !id_bytes || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_create: null");
     if (world < 1 || rank < 0 || rank >= world) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_create: rank %d of %d", rank, world);
+    const Rccl *nc = rccl();
+    if (!nc) return LPT_ERR_RCCL;
     HIP_TRY(hipSetDevice(dev->ordinal));
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
     lpt_comm *c = new (std::nothrow) lpt_comm();
     if (!c) return fail(LPT_ERR_INVALID_ARG, "out of host memory");
     c->dev = dev; c->rank = rank; c->world = world;
-    ncclResult_t st = ncclCommInitRank(&c->comm, world, id, rank);
-    if (st != ncclSuccess) { delete c; return fail(LPT_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(st)); }
+    ncclResult_t st = nc->CommInitRank(&c->comm, world, id, rank);
+    if (st != ncclSuccess) { delete c; return fail(LPT_ERR_RCCL, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, nc->GetErrorString(st)); }
     *out = c;
     return LPT_OK;
 }
@@ -1505,20 +1668,26 @@ int lpt_comm_create(lpt_device *dev, const void *id_bytes, int rank, int world, 
 int lpt_comm_destroy(lpt_comm *c) {
     if (!c) return LPT_OK;
     hipSetDevice(c->dev->ordinal);
-    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->comm && rccl()) rccl()->CommDestroy(c->comm);
     delete c;
     return LPT_OK;
 }
 
+// rank and size as RCCL itself reports them for the communicator (ncclCommUserRank / ncclCommCount), not the values
+// lpt_comm_create was called with: a host (bench.py) uses this to check that the N ranks really joined one communicator
 int lpt_comm_info(const lpt_comm *c, int *rank, int *world) {
     if (!c) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_info: null");
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    const Rccl *nc = rccl();
+    if (!nc) return LPT_ERR_RCCL;
+    int rk = -1, n = -1;
+    if (c->comm) {
+        RCCL_TRY(nc->CommUserRank(c->comm, &rk));
+        RCCL_TRY(nc->CommCount(c->comm, &n));
+    }
+    if (rank) *rank = rk;
+    if (world) *world = n;
     return LPT_OK;
 }
-
-int lpt_comm_group_begin(void) { RCCL_TRY(ncclGroupStart()); return LPT_OK; }
-int lpt_comm_group_end(void) { RCCL_TRY(ncclGroupEnd()); return LPT_OK; }
 
 int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, uint32_t *out_slots, uint32_t *out_offset) {
     if (!world || rank >= world || !tile_w || !tile_h) return fail(LPT_ERR_INVALID_ARG, "lpt_shard_layout: bad shard (rank %u of %u, tile %ux%u)", rank, world, tile_w, tile_h);
@@ -1532,8 +1701,11 @@ int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t 
 int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: null");
     if (comm && comm->dev != r->dev) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: the communicator belongs to another device");
-    r->comm = comm;
-    return comm ? lpt_renderer_set_shard(r, (uint32_t)comm->rank, (uint32_t)comm->world, 32u, 8u) : lpt_renderer_set_shard(r, 0u, 1u, 32u, 8u);
+    FLUSH_OR_RETURN(r);
+    // bind only once the shard is in place: a failed set_shard must not leave a half-bound renderer
+    const int st = comm ? lpt_renderer_set_shard(r, (uint32_t)comm->rank, (uint32_t)comm->world, 32u, 8u) : lpt_renderer_set_shard(r, 0u, 1u, 32u, 8u);
+    if (st == LPT_OK) r->comm = comm;
+    return st;
 }
 
 }  // extern "C"
@@ -1549,10 +1721,11 @@ static FrameParams shard_params(const lpt_renderer *r) {
 static uint32_t slots_of_rank(const FrameParams &p, uint32_t q) {
     return shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q + 1u) - shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q);
 }
-// `frame` (rank 0) and the staging area for packed tiles: this rank's slots, or every rank's on the root
-static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_stage, size_t bytes_per_slot = 16) {
+// `frame` (the presented whole frame: only where it is written — the root, or every rank of a reduce, which needs a valid
+// receive buffer) and the staging area for packed tiles: this rank's slots, or every rank's on the root
+static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_frame, bool want_stage, size_t bytes_per_slot = 16) {
     const size_t npx = (size_t)r->w * r->h;
-    if (!r->frame) HIP_TRY(hipMalloc(&r->frame, sizeof(float4) * std::max<size_t>(npx, 1)));
+    if ((root || want_frame) && !r->frame) HIP_TRY(hipMalloc(&r->frame, sizeof(float4) * std::max<size_t>(npx, 1)));
     if (!r->xevent) HIP_TRY(hipEventCreateWithFlags(&r->xevent, hipEventDisableTiming));
     if (!want_stage) return LPT_OK;
     const FrameParams p = shard_params(r);
@@ -1571,82 +1744,152 @@ static inline uint32_t stream_grid(const lpt_renderer *r, size_t n) {
     return (uint32_t)std::max<size_t>(1, std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)r->dev->compute_units * 8u));
 }
 
+// Phase 1 of an exchange: pack + the RCCL operations, enqueued on the renderer's stream.  Inside an open
+// lpt_comm_group_begin / _end bracket RCCL only issues them at the outermost ncclGroupEnd, so whatever consumes the received
+// data (phase 2: unpack, filter) must be enqueued after that — lpt_comm_group_end runs the deferred phase 2 of every renderer.
+static int exchange_enqueue(lpt_renderer *r, int mode) {
+    lpt_comm *c = r->comm;
+    hipStream_t s = r->stream;
+    const bool root = c->rank == 0;
+    const size_t npx = (size_t)r->w * r->h;
+    const Rccl &nc = *rccl();
+    stage_begin(r, ST_EXCHANGE, s);
+    if (r->mode != LPT_BLIT_PATHTRACE) {
+        // denoising BlitModes: the per-pixel filter inputs are what is exchanged (zero outside a rank's tiles, so the sums
+        // are gathers); rank 0 then filters the whole frame (SPEC §15.5)
+        if (mode == LPT_EXCHANGE_REDUCE) {
+            RCCL_TRY(nc.Reduce(r->den_noisy, r->den_noisy, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+            RCCL_TRY(nc.Reduce(r->den_gbuf[r->den_cur], r->den_gbuf[r->den_cur], 4 * npx, ncclInt32, ncclSum, 0, c->comm, s));
+            RCCL_TRY(nc.Reduce(r->den_motion, r->den_motion, 2 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+            return LPT_OK;
+        }
+        // owned tiles only: 40 B per owned pixel (41 MB per rank for a 3840x2160 frame on 8 GPUs, against 330 MB of reduces)
+        int st = ensure_exchange_buffers(r, root, false, true, 40);
+        if (st != LPT_OK) return st;
+        const FrameParams p = shard_params(r);
+        const uint32_t area = p.tile_w * p.tile_h;
+        unsigned char *stage = reinterpret_cast<unsigned char *>(r->xstage);
+        if (p.n_slots) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion, stage);
+        HIP_TRY(hipGetLastError());
+        if (root) {
+            RCCL_TRY(nc.GroupStart());
+            for (uint32_t q = 1; q < p.world; ++q) {
+                const uint32_t nq = slots_of_rank(p, q);
+                if (!nq) continue;
+                ncclResult_t e = nc.Recv(stage + 40u * (size_t)shard_slot_offset(p.n_tiles, p.world, area, q), 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
+                if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
+            }
+            RCCL_TRY(nc.GroupEnd());
+        } else if (p.n_slots) {
+            RCCL_TRY(nc.Send(stage, 40u * (size_t)p.n_slots, ncclUint8, 0, c->comm, s));
+        }
+        return LPT_OK;
+    }
+    int st = ensure_exchange_buffers(r, root, mode == LPT_EXCHANGE_REDUCE, mode == LPT_EXCHANGE_GATHER_TILES);
+    if (st != LPT_OK) return st;
+    const FrameParams p = shard_params(r);
+    if (mode == LPT_EXCHANGE_REDUCE) {
+        // every rank passes a valid receive buffer (only the root's is written)
+        RCCL_TRY(nc.Reduce(r->accum, r->frame, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
+        return LPT_OK;
+    }
+    const uint32_t area = p.tile_w * p.tile_h;
+    if (p.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->accum, r->xstage);   // rank 0's offset is 0
+    HIP_TRY(hipGetLastError());
+    if (root) {
+        RCCL_TRY(nc.GroupStart());
+        for (uint32_t q = 1; q < p.world; ++q) {
+            const uint32_t nq = slots_of_rank(p, q);
+            if (!nq) continue;
+            ncclResult_t e = nc.Recv(r->xstage + shard_slot_offset(p.n_tiles, p.world, area, q), 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
+            if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
+        }
+        RCCL_TRY(nc.GroupEnd());
+    } else if (p.n_slots) {
+        RCCL_TRY(nc.Send(r->xstage, 4 * (size_t)p.n_slots, ncclFloat32, 0, c->comm, s));
+    }
+    return LPT_OK;
+}
+
+// Phase 2: what reads the received data, on the same stream, behind the RCCL operations
+static int exchange_finish(lpt_renderer *r, int mode) {
+    hipStream_t s = r->stream;
+    const bool root = r->comm->rank == 0;
+    const size_t npx = (size_t)r->w * r->h;
+    if (r->mode != LPT_BLIT_PATHTRACE) {
+        if (root && mode == LPT_EXCHANGE_GATHER_TILES) {
+            const FrameParams p = shard_params(r);
+            hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, reinterpret_cast<unsigned char *>(r->xstage), r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
+        }
+        if (root && r->world != 1u) launch_filter(r, s);   // world == 1: raytrace() has filtered already
+        HIP_TRY(hipGetLastError());
+        stage_end(r, s);
+        r->den_inputs_ready = false;
+        return LPT_OK;   // the composite has written the local target on rank 0
+    }
+    if (root && mode == LPT_EXCHANGE_GATHER_TILES) {
+        const FrameParams p = shard_params(r);
+        hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->xstage, r->frame);
+        HIP_TRY(hipGetLastError());
+    }
+    stage_end(r, s);
+    r->presented = root;
+    return LPT_OK;
+}
+
+// one thread drives several communicators inside lpt_comm_group_begin / _end: the second phases wait for the outermost end
+struct DeferredFinish { lpt_renderer *r; int mode; };
+static thread_local int t_group_depth = 0;
+static thread_local std::vector<DeferredFinish> t_deferred;
+
 extern "C" {
+
+int lpt_comm_group_begin(void) {
+    const Rccl *nc = rccl();
+    if (!nc) return LPT_ERR_RCCL;
+    RCCL_TRY(nc->GroupStart());
+    ++t_group_depth;
+    return LPT_OK;
+}
+int lpt_comm_group_end(void) {
+    const Rccl *nc = rccl();
+    if (!nc) return LPT_ERR_RCCL;
+    if (t_group_depth <= 0) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_group_end without lpt_comm_group_begin");
+    const ncclResult_t e = nc->GroupEnd();
+    if (--t_group_depth > 0) { if (e != ncclSuccess) return fail(LPT_ERR_RCCL, "ncclGroupEnd failed: %s", nc->GetErrorString(e)); return LPT_OK; }
+    std::vector<DeferredFinish> todo;
+    todo.swap(t_deferred);
+    if (e != ncclSuccess) return fail(LPT_ERR_RCCL, "ncclGroupEnd failed: %s", nc->GetErrorString(e));
+    int st = LPT_OK;
+    for (const DeferredFinish &d : todo) {   // the operations are on the streams now: enqueue their consumers
+        hipSetDevice(d.r->dev->ordinal);
+        const int f = exchange_finish(d.r, d.mode);
+        if (st == LPT_OK) st = f;
+    }
+    return st;
+}
 
 int lpt_renderer_exchange(lpt_renderer *r, int mode) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: null");
     if (mode != LPT_EXCHANGE_GATHER_TILES && mode != LPT_EXCHANGE_REDUCE) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: unknown mode %d", mode);
+    FLUSH_OR_RETURN(r);
     if (!r->comm) return LPT_OK;   // single GPU: the local target is the frame
     if (!r->w || !r->h || !r->accum) return LPT_OK;
     lpt_comm *c = r->comm;
     if ((uint32_t)c->rank != r->rank || (uint32_t)c->world != r->world)
         return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: the renderer's shard (%u of %u) is not the communicator's (%d of %d); call lpt_renderer_set_comm again",
                     r->rank, r->world, c->rank, c->world);
+    if (r->mode != LPT_BLIT_PATHTRACE && (!r->den_temp || !r->den_inputs_ready)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: no denoising frame has been traced");
+    if (!rccl()) return LPT_ERR_RCCL;
     HIP_TRY(hipSetDevice(r->dev->ordinal));
-    hipStream_t s = r->stream;
-    const bool root = c->rank == 0;
-    const size_t npx = (size_t)r->w * r->h;
-    if (r->mode != LPT_BLIT_PATHTRACE) {
-        // denoising BlitModes: the per-pixel filter inputs are what is exchanged (zero outside a rank's tiles, so the sums
-        // are gathers); rank 0 then filters the whole frame (SPEC §15.5)
-        if (!r->den_temp || !r->den_inputs_ready) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange: no denoising frame has been traced");
-        if (mode == LPT_EXCHANGE_REDUCE) {
-            RCCL_TRY(ncclReduce(r->den_noisy, r->den_noisy, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
-            RCCL_TRY(ncclReduce(r->den_gbuf[r->den_cur], r->den_gbuf[r->den_cur], 4 * npx, ncclInt32, ncclSum, 0, c->comm, s));
-            RCCL_TRY(ncclReduce(r->den_motion, r->den_motion, 2 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
-        } else {
-            // owned tiles only: 40 B per owned pixel (41 MB per rank for a 3840x2160 frame on 8 GPUs, against 330 MB of reduces)
-            int st = ensure_exchange_buffers(r, root, true, 40);
-            if (st != LPT_OK) return st;
-            const FrameParams p = shard_params(r);
-            const uint32_t area = p.tile_w * p.tile_h;
-            unsigned char *stage = reinterpret_cast<unsigned char *>(r->xstage);
-            if (p.n_slots) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion, stage);
-            if (root) {
-                RCCL_TRY(ncclGroupStart());
-                for (uint32_t q = 1; q < p.world; ++q) {
-                    const uint32_t nq = slots_of_rank(p, q);
-                    if (!nq) continue;
-                    ncclResult_t e = ncclRecv(stage + 40u * (size_t)shard_slot_offset(p.n_tiles, p.world, area, q), 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
-                    if (e != ncclSuccess) { ncclGroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, ncclGetErrorString(e)); }
-                }
-                RCCL_TRY(ncclGroupEnd());
-                hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, stage, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
-            } else if (p.n_slots) {
-                RCCL_TRY(ncclSend(stage, 40u * (size_t)p.n_slots, ncclUint8, 0, c->comm, s));
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        if (root && r->world != 1u) { launch_filter(r, s); HIP_TRY(hipGetLastError()); }   // world == 1: raytrace() has filtered already
-        r->den_inputs_ready = false;
-        return LPT_OK;   // the composite has written the local target on rank 0
-    }
-    int st = ensure_exchange_buffers(r, root, mode == LPT_EXCHANGE_GATHER_TILES);
+    if (r->timings) { r->ring_pos++; harvest_slot(r, cur_slot(r)); }
+    int st = exchange_enqueue(r, mode);
     if (st != LPT_OK) return st;
-    const FrameParams p = shard_params(r);
-    if (mode == LPT_EXCHANGE_REDUCE) {
-        // every rank passes a valid receive buffer (only the root's is written)
-        RCCL_TRY(ncclReduce(r->accum, r->frame, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
-    } else {
-        const uint32_t area = p.tile_w * p.tile_h;
-        if (p.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->accum, r->xstage);   // rank 0's offset is 0
-        if (root) {
-            RCCL_TRY(ncclGroupStart());
-            for (uint32_t q = 1; q < p.world; ++q) {
-                const uint32_t nq = slots_of_rank(p, q);
-                if (!nq) continue;
-                ncclResult_t e = ncclRecv(r->xstage + shard_slot_offset(p.n_tiles, p.world, area, q), 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
-                if (e != ncclSuccess) { ncclGroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, ncclGetErrorString(e)); }
-            }
-            RCCL_TRY(ncclGroupEnd());
-            hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->xstage, r->frame);
-        } else if (p.n_slots) {
-            RCCL_TRY(ncclSend(r->xstage, 4 * (size_t)p.n_slots, ncclFloat32, 0, c->comm, s));
-        }
-        HIP_TRY(hipGetLastError());
+    if (t_group_depth > 0) {   // the RCCL operations are only issued by the outermost lpt_comm_group_end: finish there
+        t_deferred.push_back(DeferredFinish{r, mode});
+        return LPT_OK;
     }
-    r->presented = root;
-    return LPT_OK;
+    return exchange_finish(r, mode);
 }
 
 int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers) {
@@ -1654,6 +1897,8 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     if (root->rank != 0u || root->world != (uint32_t)n_peers + 1u)
         return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: root must be rank 0 of %d (is %u of %u)", n_peers + 1, root->rank, root->world);
     const bool den = root->mode != LPT_BLIT_PATHTRACE;   // denoising BlitModes: the filter inputs travel, rank 0 filters
+    FLUSH_OR_RETURN(root);
+    for (int i = 0; i < n_peers; ++i) if (peers[i]) FLUSH_OR_RETURN(peers[i]);
     if (!root->w || !root->h || !root->accum) return LPT_OK;
     std::vector<char> seen(root->world, 0);
     seen[0] = 1;
@@ -1668,7 +1913,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     if (den && (!root->den_temp || !root->den_inputs_ready)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: no denoising frame has been traced");
     const size_t bps = den ? 40 : 16;
     HIP_TRY(hipSetDevice(root->dev->ordinal));
-    int st = ensure_exchange_buffers(root, true, true, bps);
+    int st = ensure_exchange_buffers(root, true, true, true, bps);
     if (st != LPT_OK) return st;
     const FrameParams p0 = shard_params(root);
     const uint32_t area = p0.tile_w * p0.tile_h;
@@ -1680,7 +1925,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     for (int i = 0; i < n_peers; ++i) {
         lpt_renderer *q = peers[i];
         HIP_TRY(hipSetDevice(q->dev->ordinal));
-        st = ensure_exchange_buffers(q, false, true, bps);
+        st = ensure_exchange_buffers(q, false, false, true, bps);
         if (st != LPT_OK) return st;
         const FrameParams pq = shard_params(q);
         // the root's staging area may still be read by the unpack of its previous exchange

@@ -188,7 +188,7 @@ __device__ __forceinline__ void noise_shift(const DNoise &nz, uint32_t x, uint32
 
 // ------------------------------------------------------------------ ray generation
 // DENSE: every slot maps to a pixel (image is a whole number of tiles) -> queue index = slot and
-// the host presets qcount[0]; otherwise invalid slots are compacted away.
+// qcount[0] is simply the slot count; otherwise invalid slots are compacted away.
 template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Queue q, float4 *Lsum, FrameCounters *ctr) {
     __shared__ uint32_t lds[8];
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
     // the tile area is only a multiple of 64: whole blocks stay in the loop for the barriers of block_compact
     const uint32_t total = p.n_slots * p.n_samples;
     const uint32_t rounded = (total + (kBlock - 1u)) & ~(uint32_t)(kBlock - 1u);
+    if (DENSE && blockIdx.x == 0 && threadIdx.x == 0) ctr->qcount[0] = total;   // the traversal launch behind this one reads it
     for (uint32_t vslot = blockIdx.x * blockDim.x + threadIdx.x; vslot < rounded; vslot += stride) {
         const uint32_t sample = vslot / p.n_slots, slot = vslot - sample * p.n_slots;
         const uint32_t seed_counter = p.seed_counter + sample * p.max_bounces;

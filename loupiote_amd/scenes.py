@@ -6,9 +6,10 @@ with the reference or exist on this machine, so BASELINE configs 3-5 run on the 
  and every result is labelled as such:
 
   synthetic_atrium(seed=2) — Sponza stand-in: a two-storey colonnaded hall with arches, drapes,
-      a statue and an open roof; exactly 262,144 triangles, ~25 materials, ~100 instances;
-      camera = the reference's start pose (app.rs:64-67): origin (-10,1,0), dir (1,0.35,0).
-  synthetic_helmet(seed=1) — DamagedHelmet stand-in: a displaced icosphere (~70k tris), textured.
+      a statue and an open roof; exactly 262,144 triangles, 25 materials, ~100 instances, 20 x 1024^2 textures
+      (80 MB); camera = the reference's start pose (app.rs:64-67): origin (-10,1,0), dir (1,0.35,0).
+  synthetic_helmet(seed=1) — DamagedHelmet stand-in: a displaced sphere (~81k tris with its attachments and the ground),
+      5 x 2048^2 textures (84 MB), 5 materials (roughness 0.05-1, metallic 0 and 1), 1024x512 RGBE sky.
 
 A scene description is a plain dict of numpy arrays; `to_product` feeds it through the C ABI
 (`Scene.add_mesh / add_instance / ...`); the tests feed the same arrays to the oracle's numpy Scene
@@ -166,7 +167,9 @@ def sky_probe(width=512, height=256, sun_dir=(0.35, 0.8, 0.25), sun_power=60.0):
     return out
 
 
-def synthetic_atrium(seed=2, target_tris=262144, textures=True, texture_size=512):
+def synthetic_atrium(seed=2, target_tris=262144, textures=True, texture_size=1024):
+    """262,144 triangles, 24 materials (+ the dummy = 25), ~100 instances, 20 procedural
+    `texture_size`^2 RGBA8 textures (1024: 80 MB of texels, the size class of Sponza's texture set)"""
     rng = np.random.default_rng(seed)
     meshes, instances, materials, images = [], [], [], []
 
@@ -187,20 +190,34 @@ def synthetic_atrium(seed=2, target_tris=262144, textures=True, texture_size=512
         tex["floor_mra"] = T(mra_texture(texture_size, rng, 40, 160))
         tex["wall"] = T(checker_texture(texture_size, (190, 170, 140), (170, 150, 125), 8, rng, 25))
         tex["wall_mra"] = T(mra_texture(texture_size, rng, 150, 250))
-        tex["stone"] = T(checker_texture(texture_size, (205, 200, 190), (185, 180, 170), 4, rng, 30))
+        for k, (a, b, cells) in enumerate([((205, 200, 190), (185, 180, 170), 4), ((198, 190, 176), (170, 164, 150), 6),
+                                           ((188, 182, 170), (160, 152, 140), 10), ((178, 170, 160), (150, 140, 128), 3)]):
+            tex["stone%d" % k] = T(checker_texture(texture_size, a, b, cells, rng, 30))
+        tex["stone_mra"] = T(mra_texture(texture_size, rng, 120, 240))
         for k, (a, b) in enumerate([((170, 30, 30), (120, 15, 20)), ((30, 60, 150), (20, 35, 100)), ((30, 120, 50), (15, 80, 35)),
                                     ((190, 150, 40), (150, 110, 20))]):
             tex["drape%d" % k] = T(checker_texture(texture_size, a, b, 24, rng, 12))
+        tex["drape_mra"] = T(mra_texture(texture_size, rng, 190, 255))
+        for k, (a, b) in enumerate([((160, 120, 90), (120, 85, 60)), ((110, 130, 150), (80, 95, 115)), ((150, 150, 120), (105, 110, 85))]):
+            tex["trim%d" % k] = T(checker_texture(texture_size, a, b, 12, rng, 20))
+        tex["trim_mra"] = T(mra_texture(texture_size, rng, 80, 220))
+        tex["metal_mra"] = T(mra_texture(texture_size, rng, 25, 120, metal=255))
+        tex["gloss_mra"] = T(mra_texture(texture_size, rng, 10, 70))
+        assert len(images) == 20
     g = lambda k: tex.get(k, INVALID)
 
     m_floor = add_material((1, 1, 1) if textures else (0.7, 0.65, 0.6), 0.6, 0.0, g("floor"), g("floor_mra"))
     m_wall = add_material((1, 1, 1) if textures else (0.72, 0.65, 0.55), 0.95, 0.0, g("wall"), g("wall_mra"))
-    m_stone = [add_material(tuple(np.array((0.8, 0.78, 0.72)) * s) if not textures else (s, s, s), 0.8, 0.0, g("stone")) for s in (1.0, 0.92, 0.85, 0.78)]
-    m_drape = [add_material((1, 1, 1) if textures else c, 0.9, 0.0, g("drape%d" % k))
+    m_stone = [add_material(tuple(np.array((0.8, 0.78, 0.72)) * s) if not textures else (s, s, s), 0.8, 0.0, g("stone%d" % k), g("stone_mra"))
+               for k, s in enumerate((1.0, 0.92, 0.85, 0.78))]
+    m_drape = [add_material((1, 1, 1) if textures else c, 0.9, 0.0, g("drape%d" % k), g("drape_mra"))
                for k, c in enumerate([(0.65, 0.1, 0.1), (0.1, 0.2, 0.6), (0.1, 0.45, 0.18), (0.7, 0.55, 0.12)])]
-    m_metal = [add_material(c, r, 1.0) for c, r in [((0.95, 0.78, 0.35), 0.25), ((0.9, 0.9, 0.92), 0.12), ((0.72, 0.45, 0.2), 0.4)]]
-    m_gloss = [add_material(c, r, 0.0) for c, r in [((0.1, 0.1, 0.12), 0.08), ((0.6, 0.08, 0.06), 0.15), ((0.9, 0.9, 0.88), 0.2)]]
-    m_trim = [add_material(tuple(rng.uniform(0.25, 0.85, 3)), float(rng.uniform(0.3, 1.0)), 0.0) for _ in range(6)]
+    m_metal = [add_material(c, r, 1.0, INVALID, g("metal_mra") if k % 2 == 0 else INVALID)
+               for k, (c, r) in enumerate([((0.95, 0.78, 0.35), 0.25), ((0.9, 0.9, 0.92), 0.12), ((0.72, 0.45, 0.2), 0.4), ((0.56, 0.57, 0.58), 0.05)])]
+    m_gloss = [add_material(c, r, 0.0, INVALID, g("gloss_mra") if k % 2 == 1 else INVALID)
+               for k, (c, r) in enumerate([((0.1, 0.1, 0.12), 0.08), ((0.6, 0.08, 0.06), 0.15), ((0.9, 0.9, 0.88), 0.2), ((0.05, 0.25, 0.3), 0.05)])]
+    m_trim = [add_material((1, 1, 1) if textures else tuple(rng.uniform(0.25, 0.85, 3)), float(rng.uniform(0.3, 1.0)), 0.0, g("trim%d" % (k % 3)), g("trim_mra") if k < 3 else INVALID)
+              for k in range(6)]
 
     X0, X1, Z0, Z1, HY = -14.0, 14.0, -6.0, 6.0, 11.0
     ident = _translate(0, 0, 0)
@@ -249,7 +266,7 @@ def synthetic_atrium(seed=2, target_tris=262144, textures=True, texture_size=512
     for k in range(8):
         x = X0 + 3.0 + 3.3 * k
         z = (-1.2, 1.3, -0.4, 0.9)[k % 4]
-        mat = (m_metal + m_gloss)[k % 6]
+        mat = (m_metal + m_gloss)[k % 8]
         instances.append((orb, _rot_y_translate(0.3 * k, x, 0.6, z), mat))
     used = sum(meshes[bi - 1]["indices"].size // 3 for bi, _, _ in instances)
     remaining = target_tris - used
@@ -278,30 +295,44 @@ def synthetic_atrium(seed=2, target_tris=262144, textures=True, texture_size=512
     light["bitangent"] = (0, 0, 1, 1.5)
     light["origin"] = (0.0, 10.9, 0.0, 18.0)
     return {"name": "synthetic_atrium(seed=%d)" % seed, "meshes": meshes, "instances": instances, "materials": materials,
-            "images": images, "lights": [light], "probe": sky_probe(), "triangles": total,
+            "images": images, "lights": [light], "probe": sky_probe(1024, 512), "triangles": total,
             "camera": {"origin": (-10.0, 1.0, 0.0), "direction": (1.0, 0.35, 0.0)}}
 
 
-def synthetic_helmet(seed=1, textures=True, texture_size=1024):
+def synthetic_helmet(seed=1, textures=True, texture_size=2048):
+    """DamagedHelmet stand-in — a displaced sphere (69,696 triangles) with three attachments on a ground
+    plane, 5 procedural `texture_size`^2 RGBA8 textures (2048: 84 MB), 5 materials spanning roughness 0.05-1 and both
+    metallic values, a 1024x512 RGBE sky"""
     rng = np.random.default_rng(seed)
     sphere = _displaced_sphere(264, 132, 1.0, rng, amp=0.3)  # 69,696 triangles
     images, materials = [], []
-    a = m = INVALID
+    t = [INVALID] * 5
     if textures:
-        images.append(checker_texture(texture_size, (200, 200, 205), (60, 70, 90), 32, rng, 20))
-        images.append(mra_texture(texture_size, rng, 20, 255, metal=255))
-        a, m = 0, 1
-    materials.append(((1, 1, 1, 1), 1.0, 1.0, a, m))
-    materials.append(((0.8, 0.3, 0.2, 1), 0.35, 0.0, INVALID, INVALID))
+        images.append(checker_texture(texture_size, (200, 200, 205), (60, 70, 90), 32, rng, 20))       # shell: base colour
+        images.append(mra_texture(texture_size, rng, 20, 255, metal=255))                               # shell: roughness 0.08-1, metal
+        images.append(checker_texture(texture_size, (150, 140, 125), (95, 90, 80), 48, rng, 25))       # ground: base colour
+        images.append(mra_texture(texture_size, rng, 200, 255))                                         # ground: rough dielectric
+        images.append(checker_texture(texture_size, (230, 120, 40), (40, 40, 45), 8, rng, 10))         # visor / attachments
+        t = [0, 1, 2, 3, 4]
+    materials.append(((1, 1, 1, 1), 1.0, 1.0, t[0], t[1]))                    # 1 shell: textured metal
+    materials.append(((1, 1, 1, 1) if textures else (0.55, 0.5, 0.45, 1), 1.0, 0.0, t[2], t[3]))   # 2 ground: rough dielectric
+    materials.append(((1, 1, 1, 1) if textures else (0.8, 0.4, 0.15, 1), 0.05, 0.0, t[4], INVALID))  # 3 visor: smooth dielectric
+    materials.append(((0.95, 0.93, 0.88, 1), 0.3, 1.0, INVALID, INVALID))      # 4 polished metal
+    materials.append(((0.8, 0.3, 0.2, 1), 0.6, 0.0, INVALID, INVALID))         # 5 painted dielectric
     plane = _plane(64, 64, (-6, -1.4, -6), (12, 0, 0), (0, 0, 12), 6)
+    knob = _displaced_sphere(32, 16, 0.28, rng, amp=0.1)                       # 1,024 triangles, instanced three times
     light = np.zeros(1, dtype=[("normal", "<f4", 4), ("tangent", "<f4", 4), ("bitangent", "<f4", 4), ("origin", "<f4", 4)])
     light["normal"] = (0, -1, 0, 0)
     light["tangent"] = (1, 0, 0, 1.0)
     light["bitangent"] = (0, 0, 1, 1.0)
     light["origin"] = (0.0, 4.0, 0.0, 25.0)
-    return {"name": "synthetic_helmet(seed=%d)" % seed, "meshes": [sphere, plane],
-            "instances": [(1, _translate(0, 0, 0), 1), (2, _translate(0, 0, 0), 2)], "materials": materials, "images": images,
-            "lights": [light], "probe": sky_probe(), "triangles": (sphere["indices"].size + plane["indices"].size) // 3,
+    instances = [(1, _translate(0, 0, 0), 1), (2, _translate(0, 0, 0), 2),
+                 (3, _rot_y_translate(0.0, 0.0, 0.1, 1.02, (1.6, 0.9, 0.5)), 3),       # visor, towards the camera
+                 (3, _rot_y_translate(0.7, 1.12, 0.05, 0.1), 4), (3, _rot_y_translate(-0.7, -1.12, 0.05, 0.1), 5)]
+    meshes = [sphere, plane, knob]
+    total = sum(meshes[b - 1]["indices"].size // 3 for b, _, _ in instances)
+    return {"name": "synthetic_helmet(seed=%d)" % seed, "meshes": meshes, "instances": instances, "materials": materials, "images": images,
+            "lights": [light], "probe": sky_probe(1024, 512), "triangles": total,
             "camera": {"origin": (0.0, 0.6, 4.2), "direction": (0.0, -0.12, -1.0)}}
 
 

@@ -13,8 +13,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_help_and_contract_flags():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
-    for flag in ("--gpus", "--steps", "--warmup", "--exchange", "--pipeline", "--emulate-shard"):
+    for flag in ("--gpus", "--steps", "--warmup", "--exchange", "--pipeline", "--emulate-shard", "--spawn-dry-run"):
         assert flag in p.stdout
+
+
+def test_bench_starts_its_own_ranks_and_they_rendezvous():
+    """`python bench.py --gpus 2` (the driver's command shape, no launcher): the script starts two ranks of itself before
+    anything touches a GPU; with --spawn-dry-run they only meet over gloo and rank 0's line is relayed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+
+
+def test_bench_under_an_external_launcher_still_is_one_rank():
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2: WORLD_SIZE is set, nothing is re-spawned"""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-dry-run"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["ranks_seen"] == [0, 1]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_bench_refuses_more_ranks_than_gpus_loudly():
+    """on a box with fewer GPUs than --gpus the launcher says so and exits non-zero at once (no hang, no JSON line)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = __import__("time").time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
+    assert __import__("time").time() - t0 < 300
+
+
+def test_a_dying_rank_takes_the_job_down_with_its_stderr(tmp_path):
+    """a rank that dies makes the launcher stop the others and exit non-zero with that rank's stderr"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LPT_BENCH_TEST_DIE_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "rank 1 exited" in p.stderr and "LPT_BENCH_TEST_DIE_RANK" in p.stderr
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

@@ -1,0 +1,162 @@
+"""-m gpu: record-then-submit at the boundary (lpt_renderer_raytrace records, the next submission point launches; reference:
+the passes of a frame go into one encoder, renderer.rs:392-549, submitted once, app.rs:335-337).  Consecutive recorded calls
+that continue one accumulation from one view are traced as ONE wavefront — every frame below must equal, bit for bit, what the
+same calls give when each launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour), what raytrace_n gives, and
+the oracle."""
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from loupiote_amd import scenes, testing as T
+from oracle import harness
+
+pytestmark = pytest.mark.gpu
+W, H, DEPTH = 203, 117, 5
+
+
+@pytest.fixture(scope="module")
+def cornell(device, cornell_glb):
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    yield scene, sg, pr
+    pr.close()
+    sg.close()
+
+
+def _renderer(device, sg, pr, max_fused, lanes=None, size=(W, H)):
+    r = lp.Renderer(device, size)
+    r.downsample_factor = 1.0
+    r.resize(device, sg, pr, size)
+    r.set_max_bounces(DEPTH)
+    r.set_vfov(T.VFOV)
+    r.set_max_fused(max_fused)
+    if lanes:
+        r.set_lanes(lanes)
+    r.reset_accumulation()
+    r.accumulate = True
+    r.reset_ray_counts()
+    return r
+
+
+def _state(r):
+    c = r.ray_counts()
+    return (r.frame_state(), r.accumulate, (c.closest, c.shadow, c.shaded))
+
+
+def test_four_calls_equal_one_batch_equal_eager_equal_oracle(device, cornell, cornell_glb):
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    outs = []
+    for how in ("deferred", "eager", "batch", "deferred+submit"):
+        r = _renderer(device, sg, pr, 1 if how == "eager" else 0)
+        if how == "batch":
+            r.raytrace_n(view, 4)
+        else:
+            for k in range(4):
+                r.raytrace(view)
+                r.accumulate = True          # app.rs:318
+                if how == "deferred+submit" and k == 1:
+                    r.submit()               # a submission in the middle of the frame splits the wavefront, nothing else
+        outs.append((r.read_radiance(), _state(r)))
+        r.close()
+    ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
+    for img, st in outs:
+        assert img.tobytes() == ref.tobytes()
+        assert st == outs[0][1]
+        assert st[2] == (oc.closest, oc.shadow, oc.shaded)
+
+
+def _script(r, views, sg, scene):
+    """a caller that changes the view in the middle of a frame, resets, toggles accumulate, edits a setter and the scene"""
+    v0, v1 = views
+    outs = []
+    for v in (v0, v0, v1, v1, v1):               # view change mid-frame: the first two samples stay on the old view
+        r.raytrace(v)
+    outs.append(r.read_radiance())
+    outs.append(_state(r))
+    r.raytrace(v1); r.raytrace(v1)
+    r.reset_accumulation()                       # frame_count = 1, accumulate = false: the two calls above are dropped from the mean
+    r.raytrace(v0)                               # accumulate == false: overwrites
+    r.raytrace(v0)                               # still false: overwrites again
+    r.accumulate = True
+    r.raytrace(v0); r.raytrace(v0); r.raytrace(v0)
+    outs.append(_state(r))                       # reading the counters is a submission point
+    r.raytrace(v0)
+    r.set_max_bounces(2)                         # a setter the passes read: what is recorded keeps the old depth
+    r.raytrace(v0); r.raytrace(v0)
+    r.set_max_bounces(DEPTH)
+    outs.append(r.read_radiance())
+    outs.append(r.read_pixels())
+    # scene edit between recorded calls: the first call must see the scene as it was
+    r.reset_accumulation(); r.accumulate = True
+    r.raytrace(v0)
+    m = np.eye(4, dtype=np.float32); m[3, :3] = (0.4, 0.2, -0.3)
+    scene.set_instance_transform(2, m.reshape(16))
+    sg.update_instances(scene)
+    r.raytrace(v0)
+    outs.append(r.read_radiance())
+    scene.set_instance_transform(2, np.eye(4, dtype=np.float32).reshape(16))
+    sg.update_instances(scene)
+    outs.append(_state(r))
+    return outs
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_any_call_sequence_equals_the_eager_launches(device, cornell, lanes):
+    scene, sg, pr = cornell
+    views = (T.look(T.CORNELL_EYE, T.CORNELL_DIR), T.look((0.5, 0.4, 12.0), (-0.05, 0.02, -1.0)))
+    results = []
+    for max_fused in (1, 0, 3):
+        r = _renderer(device, sg, pr, max_fused, lanes)
+        results.append(_script(r, views, sg, scene))
+        r.close()
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            if isinstance(a, np.ndarray):
+                assert a.tobytes() == b.tobytes()
+            else:
+                assert a == b
+
+
+def test_batches_are_cut_at_the_cap_and_nothing_is_lost_on_destroy(device, cornell):
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    r = _renderer(device, sg, pr, 3)
+    for _ in range(7):                           # 3 + 3 launch when full, 1 stays recorded
+        r.raytrace(view)
+    assert r.frame_state() == (8, 7 * DEPTH)     # the protocol state moves at record time
+    img = r.read_radiance()
+    r.raytrace(view)                             # recorded, never submitted
+    r.close()
+    e = _renderer(device, sg, pr, 1)
+    for _ in range(7):
+        e.raytrace(view)
+    assert img.tobytes() == e.read_radiance().tobytes()
+    e.close()
+
+
+def test_atrium_frame_of_the_unchanged_caller_equals_the_batched_frame(device):
+    desc = scenes.synthetic_atrium(texture_size=128)
+    sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
+    pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    global DEPTH
+    keep, DEPTH = DEPTH, 8
+    try:
+        a = _renderer(device, sg, pr, 0, size=(480, 270))
+        for _ in range(4):
+            a.raytrace(view)
+        dst = lp.pinned_array((270, 480, 4))     # page-locked read-back destination (lpt_host_alloc)
+        ia = a.read_radiance(out=dst).copy()
+        b = _renderer(device, sg, pr, 0, size=(480, 270))
+        b.raytrace_n(view, 4)
+        assert ia.tobytes() == b.read_radiance().tobytes()
+        assert _state(a) == _state(b)
+        a.close(); b.close()
+    finally:
+        DEPTH = keep
+    pr.close()
+    sg.close()
