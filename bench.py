@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
     ap.add_argument("--eager", action="store_true", help="experiments: every raytrace() launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour)")
+    ap.add_argument("--max-fused", type=int, default=0, help="experiments: lpt_renderer_set_max_fused(n) on the timed renderer (0 = the library's default)")
+    ap.add_argument("--lanes", type=int, default=0, help="experiments: wavefront lanes of the timed renderer (0 = the library's default)")
     ap.add_argument("--pageable", action="store_true", help="experiments: read_radiance() into pageable host memory")
     ap.add_argument("--spawn-dry-run", action="store_true", help="start the ranks and rendezvous over gloo only: no GPU is touched (CPU test of the launcher)")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="seconds the self-started ranks may take")
@@ -324,7 +326,9 @@ def run(args):
         torch.cuda.synchronize()
 
     # ================================================================== value: the SURVEY §8d span on ONE renderer
-    r = make_renderer(comms[0] if comms else None)
+    r = make_renderer(comms[0] if comms else None, lanes=args.lanes or None)
+    if args.max_fused:
+        r.set_max_fused(args.max_fused)
     dst = None if args.pageable else lp.pinned_array((HEIGHT, WIDTH, 4))   # page-locked read-back destination (lpt_host_alloc)
     last = {}
 

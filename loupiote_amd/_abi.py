@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libloupiote_hip.so")
+LIB_PATH = os.environ.get("LPT_LIB_PATH") or os.path.join(_HERE, "libloupiote_hip.so")   # LPT_LIB_PATH: A/B builds of experiments (csrc/Makefile `variant`)
 
 LPT_OK = 0
 LPT_ERR_FILE_NOT_FOUND = 1

@@ -37,7 +37,7 @@ def test_config2_cornell_1024_4spp_depth8(device, cornell_glb):
 def test_config3_helmet_standin(device):
     from oracle import orc
     desc = scenes.synthetic_helmet()
-    assert desc["triangles"] > 69000 and len(desc["images"]) == 2
+    assert desc["triangles"] > 69000 and len(desc["images"]) == 5 and len(desc["materials"]) == 5
     osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
     sg, pr, r, view = _renderer(device, desc, 480, 270, 8)
     r.reset_accumulation()

@@ -242,6 +242,36 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned q
             REP16(X)
 #undef X
         }
+        else if (OP == 44) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2 clamp" : "+v"(v[i]) : "v"(a), "v"(b));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 45) {
+#define X(i) asm volatile("v_fma_f32 %0, |%0|, %1, |%2|" : "+v"(v[i]) : "v"(a), "v"(b));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 46) {
+#define X(i) asm volatile("v_add_f32_e64 %0, %0, %1 clamp" : "+v"(v[i]) : "v"(a));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 47) {
+#define X(i) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(v[i]) : "v"(a));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 48) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2 mul:2" : "+v"(v[i]) : "v"(a), "v"(b));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 49) {
+#define X(i) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %2, 0, %3, vcc" : : "v"(v[i]), "v"(a), "v"(u[i]), "v"(q) : "vcc");
+            REP16(X)
+#undef X
+        }
     }
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += v[i];
@@ -334,6 +364,11 @@ int main() {
         run<41>("cmp_e64vcc+cnd_e64vcc", 32, d, w);
         run<42>("v_addc_co_u32_e32", 16, d, w);
         run<43>("v_readfirstlane", 16, d, w);
+        run<44>("v_fma_f32 clamp", 16, d, w);
+        run<45>("v_fma_f32 |abs|", 16, d, w);
+        run<46>("v_add_f32_e64 clamp", 16, d, w);
+        run<47>("v_mul_f32_e64", 16, d, w);
+        run<48>("v_fma_f32 mul:2", 16, d, w);
     }
     return 0;
 }
