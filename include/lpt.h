@@ -331,9 +331,10 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view_transform[16]);
 /* replaces: queue.submit(Some(encoder.finish())) (crates/standalone/src/app.rs:335-337): launches what has been recorded.
  * Asynchronous (nothing waits for the GPU); a no-op when nothing is pending. */
 int lpt_renderer_submit(lpt_renderer *r);
-/* new (no reference knob): the largest number of recorded calls one submission fuses.  0 = automatic (about 16 M rays per
- * wavefront: 8 samples at 1920x1080, 2 at 3840x2160; a full batch is submitted at once), 1 = every raytrace() launches
- * immediately (the round-2 behaviour), up to 64.  Costs ray-queue memory: 176 B per ray in flight and wavefront lane. */
+/* new (no reference knob): the largest number of recorded calls one submission fuses.  0 = automatic (about 4 M rays per
+ * wavefront: 2 samples at 1920x1080, 1 at 3840x2160, 32 at 480x270; a full batch is submitted at once, consecutive batches
+ * take the renderer's wavefront lanes in turn and overlap), 1 = every raytrace() launches immediately (the round-2
+ * behaviour), up to 64.  Costs ray-queue memory: 176 B per ray in flight and wavefront lane. */
 int lpt_renderer_set_max_fused(lpt_renderer *r, uint32_t n);
 /* Build-only batching of the call above: exactly equivalent (bit for bit) to
  * n x { lpt_renderer_raytrace(r, view); accumulate = true (app.rs:318); } but traced as ONE wavefront

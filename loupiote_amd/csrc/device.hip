@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -106,6 +107,10 @@ struct lpt_scene_gpu {
     DScene d{};
     void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr;
     void *materials = nullptr, *lights = nullptr, *texels = nullptr, *images = nullptr, *srgb_lut = nullptr;
+    // paired textures (kernels.h DScene::pair_texels): (albedo image, mra image) -> pair index, for the materials whose two
+    // textures have one size; the shading records of such materials carry kPairedBit | pair index instead of two image ids
+    void *pair_texels = nullptr, *pair_images = nullptr;
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> pair_map;
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
     void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
@@ -165,7 +170,7 @@ struct lpt_renderer {
     // view that continue one accumulation fuse into ONE wavefront of `n` samples per pixel; the host-side protocol state
     // (frame_count, seed, frame_back) moves at record time, the snapshot below is what the launches use.
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
-    uint32_t max_fused = 0;    // samples one submission may fuse; 0 = auto (about 16 M rays per wavefront), 1 = every call launches at once
+    uint32_t max_fused = 0;    // samples one submission may fuse; 0 = auto (about 4 M rays per wavefront), 1 = every call launches at once
     int mode = LPT_BLIT_PATHTRACE;
     // build-only knobs
     uint32_t max_bounces = 3, user_seed = 0;
@@ -368,8 +373,16 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
 #undef SCR
 }
 
+// the material as the shading records carry it: a material whose albedo and mra textures were paired at upload names the pair
+static lpt_material device_material(const lpt_scene_gpu *sg, const lpt_material &m) {
+    lpt_material d = m;
+    const auto it = sg->pair_map.find(std::make_pair(m.albedo_texture, m.mra_texture));
+    if (it != sg->pair_map.end()) { d.albedo_texture = kPairedBit | it->second; d.mra_texture = LPT_INVALID_INDEX; }
+    return d;
+}
+
 // kernel arguments for re-baking instance i on the device (k_bake_instance)
-static int make_bake_args(const lpt_scene &scene, size_t i, uint32_t first, uint32_t n, BakeArgs &a) {
+static int make_bake_args(const lpt_scene_gpu *sg, const lpt_scene &scene, size_t i, uint32_t first, uint32_t n, BakeArgs &a) {
     const lpt_instance &now = scene.instances[i];
     const lpt_blas_entry &e = scene.entries[now.blas_index];
     if (e.index_count / 3u != n) return fail(LPT_ERR_INVALID_ARG, "triangle count of instance %zu changed since the upload", i);
@@ -380,7 +393,8 @@ static int make_bake_args(const lpt_scene &scene, size_t i, uint32_t first, uint
     a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
     a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
     a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
-    memcpy(a.mat, &scene.materials[now.material_index < scene.materials.size() ? now.material_index : 0u], 32);
+    const lpt_material dm = device_material(sg, scene.materials[now.material_index < scene.materials.size() ? now.material_index : 0u]);
+    memcpy(a.mat, &dm, 32);
     return LPT_OK;
 }
 
@@ -447,7 +461,7 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     flush_device(sg->dev);
     hipDeviceSynchronize();   // renderers trace on their own streams: frames still in flight read what is freed here
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
-                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena};
+                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena, sg->pair_texels, sg->pair_images};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
     return LPT_OK;
@@ -495,6 +509,41 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
         return st;                                                             \
     }
     static_assert(sizeof(float4) * kTriRec == 128 && sizeof(lpt_vertex) * 3 == 96 && sizeof(lpt_material) == 32, "shading record layout");
+    // Paired textures: a material that has both an albedo and an mra texture of one size gets the two interleaved — 8 B per texel
+    // (albedo RGBA8, mra RGBA8) in 4x4-texel tiles of 128 B — so that ONE set of four taps serves both lookups of a shaded hit:
+    // 1.56 cache lines per hit instead of 2 x 1.4 (k_shade is bound by HBM traffic, most of it texels).  Lossless: the taps and
+    // the filter arithmetic are those of two separate lookups.  The separate images stay in the atlas for every other use.
+    std::vector<DImage> pair_descs;
+    std::vector<uint64_t> pair_texels;
+    {
+        const char *ev = getenv("LPT_PAIR_TEXTURES");
+        const bool enable = !ev || atoi(ev) != 0;
+        const size_t budget = (size_t)1 << 30;   // bytes of paired texels per scene
+        for (const lpt_material &m : scene->materials) {
+            if (!enable) break;
+            const uint32_t a = m.albedo_texture, r = m.mra_texture;
+            if (a >= scene->images.size() || r >= scene->images.size()) continue;
+            const Image &ia = scene->images[a], &ir = scene->images[r];
+            if (ia.width != ir.width || ia.height != ir.height || !ia.width || !ia.height) continue;
+            if (sg->pair_map.count(std::make_pair(a, r))) continue;
+            const uint32_t tx = (ia.width + 3u) / 4u, ty = (ia.height + 3u) / 4u;
+            if ((pair_texels.size() + (size_t)tx * ty * 16u) * 8u > budget || pair_texels.size() + (size_t)tx * ty * 16u > 0x3FFFFFFFull) continue;
+            DImage di;
+            di.offset = (uint32_t)pair_texels.size();   // in 8-byte texels
+            di.width = ia.width; di.height = ia.height; di.pad = tx;
+            const size_t base = pair_texels.size();
+            pair_texels.resize(base + (size_t)tx * ty * 16u, 0);
+            for (uint32_t y = 0; y < ia.height; ++y)
+                for (uint32_t x = 0; x < ia.width; ++x) {
+                    uint32_t wa, wr;
+                    memcpy(&wa, &ia.rgba8[4u * ((size_t)y * ia.width + x)], 4);
+                    memcpy(&wr, &ir.rgba8[4u * ((size_t)y * ir.width + x)], 4);
+                    pair_texels[base + ((size_t)(y >> 2) * tx + (x >> 2)) * 16u + (y & 3u) * 4u + (x & 3u)] = (uint64_t)wa | ((uint64_t)wr << 32);
+                }
+            sg->pair_map[std::make_pair(a, r)] = (uint32_t)pair_descs.size();
+            pair_descs.push_back(di);
+        }
+    }
     if (!gpu_build) {
         UP(nodes, acc.nodes)
         UP(woop, acc.woop)
@@ -504,7 +553,8 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
         std::vector<TriRec> recs(acc.tri_material.size());
         for (size_t t = 0; t < recs.size(); ++t) {
             memcpy(recs[t].v, &acc.tri_verts[3 * t], 96);
-            memcpy(&recs[t].v[6], &scene->materials[acc.tri_material[t] < scene->materials.size() ? acc.tri_material[t] : 0], 32);
+            const lpt_material dm = device_material(sg, scene->materials[acc.tri_material[t] < scene->materials.size() ? acc.tri_material[t] : 0]);
+            memcpy(&recs[t].v[6], &dm, 32);
         }
         UP(tri_verts, recs)
     } else {
@@ -532,6 +582,8 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     }
     UP(images, descs)
     UP(texels, texels)
+    UP(pair_images, pair_descs)
+    UP(pair_texels, pair_texels)
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) {
         const double c = (double)i / 255.0;
@@ -569,6 +621,9 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     d.texels = (const uint8_t *)sg->texels;
     d.images = (const DImage *)sg->images;
     d.srgb_lut = (const float *)sg->srgb_lut;
+    d.pair_texels = (const uint2 *)sg->pair_texels;
+    d.pair_images = (const DImage *)sg->pair_images;
+    d.n_pairs = (uint32_t)pair_descs.size();
     d.n_tris = n_tris;
     d.n_materials = (uint32_t)scene->materials.size();
     d.n_lights = (uint32_t)scene->lights.size();
@@ -590,7 +645,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
             const uint32_t first = sg->inst_first[i], cnt = sg->inst_count[i];
             if (!cnt) continue;
             BakeArgs a;
-            st = make_bake_args(*scene, i, first, cnt, a);
+            st = make_bake_args(sg, *scene, i, first, cnt, a);
             if (st == LPT_OK)
                 hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
                                    (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
@@ -644,7 +699,7 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         if (n) {
             // re-bake on the device: the object-space mesh is resident, only the transform travels
             BakeArgs a;
-            int bst = make_bake_args(*scene, i, first, n, a);
+            int bst = make_bake_args(sg, *scene, i, first, n, a);
             if (bst != LPT_OK) return bst;
             hipLaunchKernelGGL(k_bake_instance, dim3(div_up(n, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
                                (float4 *)sg->tri_verts, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
@@ -694,7 +749,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
         const uint32_t first = sg->inst_first[i], cnt = sg->inst_count[i];
         if (!cnt) continue;
         BakeArgs a;
-        int bst = make_bake_args(*scene, i, first, cnt, a);
+        int bst = make_bake_args(sg, *scene, i, first, cnt, a);
         if (bst != LPT_OK) { hipFree(woop_prim); return bst; }
         hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
                            (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
@@ -1402,7 +1457,10 @@ static uint32_t fuse_cap(const lpt_renderer *r) {
     if (r->max_fused) return r->max_fused;
     uint32_t tiles_x, n_tiles, n_slots;
     shard_geometry(r, tiles_x, n_tiles, n_slots);
-    return std::max(1u, std::min(64u, (1u << 24) / std::max(n_slots, 1u)));   // about 16 M rays (2.8 GB of ray state) per wavefront
+    // about 4 M rays per wavefront: 2 samples at 1920x1080, so that the 4 samples of a frame leave as two wavefronts on the
+    // renderer's two lanes and the shading of one overlaps the traversal of the other (measured: 13.30 ms per frame against
+    // 13.68 for one 8 M-ray wavefront and 14.1 for four 2 M-ray ones)
+    return std::max(1u, std::min(64u, (1u << 22) / std::max(n_slots, 1u)));
 }
 
 // Records ONE raytrace() call: the host-side protocol of Renderer::raytrace moves now (frame_back :401, seed :453/:487,

@@ -267,6 +267,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             progressive = m == 0xC2;
             H = be16(seg + 1); W = be16(seg + 3); ncomp = seg[5];
             if ((ncomp != 1 && ncomp != 3) || !W || !H || n < 6u + 3u * (size_t)ncomp) return false;
+            // untrusted header: an absolute bound on what a file may make the decoder allocate (the renderer's own limit is
+            // 8192 x 8192): 67 M pixels = 268 MB of RGBA8, 200 MB of progressive coefficients
+            if ((size_t)W * (size_t)H > (size_t)8192 * 8192) return false;
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = seg[6 + 3 * c]; comp[c].h = seg[7 + 3 * c] >> 4; comp[c].v = seg[7 + 3 * c] & 15; comp[c].tq = seg[8 + 3 * c];
                 if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) return false;
@@ -312,20 +315,25 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             Reader r{data + off + len, data + size};
             for (int k = 0; k < ns; ++k) comp[which[k]].pred = 0;
             int count = 0;
-            auto restart_here = [&]() {
-                if (restart && count && count % restart == 0) {
+            // false: the entropy-coded data ended (a marker other than the expected RSTn, or the file) before this block —
+            // a truncated scan must fail here instead of walking every remaining block on zero bits
+            auto restart_here = [&]() -> bool {
+                const bool at_restart = restart && count && count % restart == 0;
+                if ((r.marker || !r.ok) && !at_restart) return false;
+                if (at_restart) {
                     skip_to_after_rst(r);
                     for (int k = 0; k < ns; ++k) comp[which[k]].pred = 0;
                     sc.eobrun = 0;
                 }
                 ++count;
+                return true;
             };
             if (ns == 1) {   // non-interleaved: the component's own blocks, row by row
                 Comp &cp = comp[which[0]];
                 const int bpr = cp.bw / 8;
                 for (int by = 0; by < cp.nby; ++by)
                     for (int bx = 0; bx < cp.nbx; ++bx) {
-                        restart_here();
+                        if (!restart_here()) return false;
                         int16_t *cf = &cp.coef[((size_t)by * bpr + bx) * 64];
                         const bool ok = sc.ss == 0 ? prog_dc(r, hdc[cp.td], cp, cf, sc) : prog_ac(r, hac[cp.ta], cf, sc);
                         if (!ok) return false;
@@ -333,7 +341,7 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             } else {         // interleaved (DC scans): MCU by MCU
                 for (int my_ = 0; my_ < my; ++my_)
                     for (int mx_ = 0; mx_ < mx; ++mx_) {
-                        restart_here();
+                        if (!restart_here()) return false;
                         for (int k = 0; k < ns; ++k) {
                             Comp &cp = comp[which[k]];
                             const int bpr = cp.bw / 8;
@@ -370,7 +378,9 @@ bool decode_jpeg(const uint8_t *data, size_t size, Image &out) {
             int count = 0;
             for (int my_ = 0; my_ < my; ++my_)
                 for (int mx_ = 0; mx_ < mx; ++mx_) {
-                    if (restart && count && count % restart == 0) {
+                    const bool at_restart = restart && count && count % restart == 0;
+                    if ((r.marker || !r.ok) && !at_restart) return false;   // the scan ended before its last MCU
+                    if (at_restart) {
                         skip_to_after_rst(r);
                         for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
                     }

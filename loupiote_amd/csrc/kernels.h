@@ -46,8 +46,13 @@ struct DScene {
     const uint8_t *texels;       // RGBA8, all images back to back
     const DImage *images;
     const float *srgb_lut;       // 256 entries
-    uint32_t n_tris, n_materials, n_lights, n_images;
+    // paired textures: (albedo RGBA8, mra RGBA8) per texel, 4x4-texel tiles of 128 B, for materials whose two textures have one
+    // size; such a material's record carries kPairedBit | pair index as its albedo texture (device.hip: device_material)
+    const uint2 *pair_texels;
+    const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row
+    uint32_t n_tris, n_materials, n_lights, n_images, n_pairs;
 };
+constexpr uint32_t kPairedBit = 0x40000000u;
 
 struct DProbe { const uint8_t *rgbe; uint32_t w, h; };
 struct DNoise { const uint8_t *rgba; uint32_t w, h, enabled; };
@@ -693,6 +698,42 @@ __device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *
     return make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// Both textures of a material from ONE set of four taps (paired texels: x = albedo RGBA8, y = mra RGBA8).  The coordinates, the
+// weights and every product are those of two texture_lookup calls on images of this size, so the result is theirs bit for bit;
+// only albedo.rgb (sRGB-decoded) and mra.g / mra.b are produced, which is all the shading reads.
+__device__ __forceinline__ void texture_lookup_pair(const DScene &sc, const float *lut, uint32_t pair, float u, float v, f3 &albedo, float &mra_g, float &mra_b) {
+    const DImage im = sc.pair_images[pair];
+    const int W = (int)im.width, H = (int)im.height;
+    float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    int x0 = wrap_i((int)x0f, W), x1 = wrap_next(x0, W);
+    int y0 = wrap_i((int)y0f, H), y1 = wrap_next(y0, H);
+    const uint2 *base = sc.pair_texels + im.offset;
+    const uint32_t tiles_x = im.pad;
+    const uint32_t r0 = ((uint32_t)y0 >> 2) * tiles_x * 16u + ((uint32_t)y0 & 3u) * 4u, r1 = ((uint32_t)y1 >> 2) * tiles_x * 16u + ((uint32_t)y1 & 3u) * 4u;
+    const uint32_t c0 = ((uint32_t)x0 >> 2) * 16u + ((uint32_t)x0 & 3u), c1 = ((uint32_t)x1 >> 2) * 16u + ((uint32_t)x1 & 3u);
+    const uint2 p00 = base[r0 + c0], p10 = base[r0 + c1], p01 = base[r1 + c0], p11 = base[r1 + c1];
+    float a[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float c00 = lut[(p00.x >> (8 * ch)) & 0xFFu], c10 = lut[(p10.x >> (8 * ch)) & 0xFFu];
+        const float c01 = lut[(p01.x >> (8 * ch)) & 0xFFu], c11 = lut[(p11.x >> (8 * ch)) & 0xFFu];
+        float top = c00 * (1.0f - tx) + c10 * tx, bot = c01 * (1.0f - tx) + c11 * tx;
+        a[ch] = top * (1.0f - ty) + bot * ty;
+    }
+    albedo = mk3(a[0], a[1], a[2]);
+    float m[2];
+#pragma unroll
+    for (int ch = 1; ch < 3; ++ch) {
+        const float c00 = (float)((p00.y >> (8 * ch)) & 0xFFu) * 0.003921568859368563f, c10 = (float)((p10.y >> (8 * ch)) & 0xFFu) * 0.003921568859368563f;
+        const float c01 = (float)((p01.y >> (8 * ch)) & 0xFFu) * 0.003921568859368563f, c11 = (float)((p11.y >> (8 * ch)) & 0xFFu) * 0.003921568859368563f;
+        float top = c00 * (1.0f - tx) + c10 * tx, bot = c01 * (1.0f - tx) + c11 * tx;
+        m[ch - 1] = top * (1.0f - ty) + bot * ty;
+    }
+    mra_g = m[0]; mra_b = m[1];
+}
+
 __device__ __forceinline__ f3 rgbe_decode(uchar4 p) {
     const uint32_t e = p.w;
     float scale = 0.0f;
@@ -851,13 +892,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     f3 base = mk3(mc.x, mc.y, mc.z);
                     float rough = mp.x, metal = mp.y;
                     const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
-                    if (atex < sc.n_images) {
-                        const float4 tex = texture_lookup(sc, s_lut, atex, tu, tvv, true);
-                        base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
-                    }
-                    if (mtex < sc.n_images) {
-                        const float4 tex = texture_lookup(sc, s_lut, mtex, tu, tvv, false);
-                        rough *= tex.y; metal *= tex.z;
+                    if ((atex >> 30) == 1u) {   // kPairedBit set, not LPT_INVALID_INDEX: both textures of the material from one set of taps
+                        f3 alb;
+                        float mg, mb;
+                        texture_lookup_pair(sc, s_lut, atex & ~kPairedBit, tu, tvv, alb, mg, mb);
+                        base.x *= alb.x; base.y *= alb.y; base.z *= alb.z;
+                        rough *= mg; metal *= mb;
+                    } else {
+                        if (atex < sc.n_images) {
+                            const float4 tex = texture_lookup(sc, s_lut, atex, tu, tvv, true);
+                            base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
+                        }
+                        if (mtex < sc.n_images) {
+                            const float4 tex = texture_lookup(sc, s_lut, mtex, tu, tvv, false);
+                            rough *= tex.y; metal *= tex.z;
+                        }
                     }
                     g_n = Ns; g_P = P;
                     g_alb = mk3(clampf(base.x, 0.0f, 1.0f), clampf(base.y, 0.0f, 1.0f), clampf(base.z, 0.0f, 1.0f));

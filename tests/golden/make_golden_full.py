@@ -7,12 +7,15 @@ sizes the bench runs, not only to a live oracle at reduced sizes.
   cfg3  DamagedHelmet stand-in + sky probe, 1920x1080, 8 spp, depth 8
   cfg4  Sponza stand-in (the bench workload), 1920x1080, 4 spp, depth 8
   cfg5p the same scene, 3840x2160, depth 8: the first 2 of the 64 progressive samples
+  cfg5p64 the same, all 64 progressive samples (sha256, ray counts, means and windows of the 64-spp frame)
   cfg5t the same, BlitMode::Temporal, 2 frames (1 spp each): composite output, history
+  cfg5d the same, BlitMode::DenoisedPathrace (temporal + 4 a-trous + composite), 2 frames: output, history
 
 Per config: sha256 of the whole resolved float32 frame, exact ray counts (closest, shadow, shaded), per-channel
 means, the oracle's own nodes / triangle tests per ray (its private BVH2; informational), and four 32x32 windows.
 The reference cannot produce vectors for this path: these pin the ORACLE (itself pinned by
-tests/test_oracle_kat.py), generated in the build container by this script.  Run from the repo root (~5 min on 8 cores)."""
+tests/test_oracle_kat.py), generated in the build container by this script.  Run from the repo root (~25 min on 8 cores, most of it the 64-spp 4K frame;
+`--skip-64spp` keeps the committed cfg5p64 entries)."""
 import hashlib
 import os
 import sys
@@ -74,6 +77,20 @@ def main():
         img = den.frame(view, mode=2)
     _, _, _, hist = den.read()
     record(out, "cfg5t", img, None, {"history_sha256": hashlib.sha256(np.ascontiguousarray(hist).tobytes()).hexdigest()})
+    del den
+    den = orc.Denoiser(osc, 3840, 2160, T.VFOV, 8)
+    for _ in range(2):
+        img = den.frame(view, mode=1)   # BlitMode::DenoisedPathrace: temporal + a-trous x 4 + composite (asvgf.rs:278-290)
+    _, _, rad, hist = den.read()
+    record(out, "cfg5d", img, None, {"history_sha256": hashlib.sha256(np.ascontiguousarray(hist).tobytes()).hexdigest(),
+                                     "radiance_sha256": hashlib.sha256(np.ascontiguousarray(rad).tobytes()).hexdigest()})
+    del den
+    if "--skip-64spp" in sys.argv and os.path.exists(path):
+        old = dict(np.load(path))
+        out.update({k: v for k, v in old.items() if k.startswith("cfg5p64_")})
+    else:
+        acc, cnt = osc.render(3840, 2160, view, T.VFOV, 8, frames=64, want_counters=True)
+        record(out, "cfg5p64", orc.resolve(acc), cnt)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "full_configs.npz"), **out)
     print("done in %.0f s" % (time.time() - t0))
 

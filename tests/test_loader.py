@@ -378,6 +378,34 @@ def test_hdr_writer_round_trip(tmp_path):
     assert np.all(np.abs(dec - clean) <= m[..., None] / 128.0 + 1e-30)
 
 
+def test_jpeg_hostile_headers_and_truncated_scans_fail_fast():
+    """untrusted input: a frame header may not make the decoder allocate more than the renderer's 8192 x 8192 bound, and a scan
+    whose entropy-coded data stops early (a marker or the end of the file before its last block) fails instead of walking every
+    remaining block — of every remaining scan — on zero bits"""
+    import time
+    rgb = _smooth_rgb(640, 480)
+    for kw in (dict(quality=85, subsampling=2, progressive=True), dict(quality=85, subsampling=2), dict(quality=85, subsampling=0, restart_marker_rows=1)):
+        raw = _jpeg(rgb, **kw)
+        assert lp.decode_image(raw).shape == (640, 480, 4)
+        sos = raw.index(b"\xff\xda")
+        for cut in (sos + 40, sos + (len(raw) - sos) // 3, len(raw) - 200):
+            with pytest.raises(lp.Error):
+                lp.decode_image(raw[:cut] + b"\xff\xd9")
+    # a 1 MB file whose SOF2 announces 65535 x 65535 (4:2:0): rejected at the header, nothing allocated, no time spent
+    raw = bytearray(_jpeg(rgb, quality=85, subsampling=2, progressive=True))
+    sof = raw.index(b"\xff\xc2")
+    raw[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    raw += bytes(1 << 20)
+    t0 = time.time()
+    with pytest.raises(lp.Error):
+        lp.decode_image(bytes(raw))
+    assert time.time() - t0 < 1.0
+    # 8192 x 8192 itself is inside the bound; 8192 x 8200 is not (header check only: the scan data is that of the small image)
+    raw[sof + 5:sof + 9] = (8200).to_bytes(2, "big") + (8192).to_bytes(2, "big")
+    with pytest.raises(lp.Error):
+        lp.decode_image(bytes(raw))
+
+
 def test_decode_image_export(tmp_path):
     """lpt_decode_image: the decoder behind load_blue_noise (app.rs:116-132) — PNG exact, JPEG within the loader's tolerance"""
     from PIL import Image

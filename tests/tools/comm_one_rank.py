@@ -82,6 +82,38 @@ def main():
         shared.exchange(lp.EXCHANGE_GATHER_TILES)
         assert L.lpt_comm_group_end() == 0
         assert shared.read_radiance().tobytes() == plain.read_radiance().tobytes(), frame
+    # two communicators driven by ONE thread, both exchanges of a frame inside one group bracket (the single-process /
+    # several-GPU host of INTEGRATION.md): the RCCL operations are issued by the outermost lpt_comm_group_end, which then
+    # enqueues what consumes them (unpack, filter passes) for EVERY renderer of the bracket — path tracing and denoising
+    assert L.lpt_comm_group_begin() == 0
+    comm3 = lp.Comm(dev, lp.Comm.unique_id(), 0, 1)
+    assert L.lpt_comm_group_end() == 0
+    view2 = T.look((0.4, 0.5, 12.5), (-0.03, 0.0, -1.0))
+    for mode in (lp.BlitMode.Pahtrace, lp.BlitMode.DenoisedPathrace):
+        pa, pb, sa, sb = mk(), mk(), mk(), mk()          # fresh renderers: the ASVGF history starts empty on all four
+        sa.set_comm(comm2); sa.set_resources(dev, sg, pr)
+        sb.set_comm(comm3); sb.set_resources(dev, sg, pr)
+        for r in (pa, pb, sa, sb):
+            r.set_blit_mode(mode)
+            r.reset_accumulation()
+            r.accumulate = mode == lp.BlitMode.Pahtrace
+        for frame in range(3):
+            pa.raytrace(view); sa.raytrace(view)
+            pb.raytrace(view2); sb.raytrace(view2)
+            assert L.lpt_comm_group_begin() == 0
+            assert L.lpt_comm_group_begin() == 0          # brackets nest: only the outermost end issues
+            sa.exchange(lp.EXCHANGE_GATHER_TILES)
+            assert L.lpt_comm_group_end() == 0
+            sb.exchange(lp.EXCHANGE_REDUCE if frame % 2 else lp.EXCHANGE_GATHER_TILES)
+            assert L.lpt_comm_group_end() == 0
+            assert sa.read_radiance().tobytes() == pa.read_radiance().tobytes(), (mode, frame)
+            assert sb.read_radiance().tobytes() == pb.read_radiance().tobytes(), (mode, frame)
+        for r in (sa, sb):
+            r.set_comm(None)
+        for r in (pa, pb, sa, sb):
+            r.close()
+    assert L.lpt_comm_group_end() != 0                    # an end without a begin is an error, not a crash
+    comm3.close()
     shared.set_comm(None)
     comm2.close()
     for r in (plain, shared):

@@ -9,8 +9,9 @@
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 constexpr int ITER = 4096;
 
+// cyc[block] = s_memtime ticks (shader cycles: the clock the SIMD really ran at, DVFS included) the wave spent in the timed loop
 template <int OP>
-__global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned qa) {
+__global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned qa, unsigned long long *cyc) {
     float v[16];
     typedef float v2f __attribute__((ext_vector_type(2)));
     v2f w[8];
@@ -21,6 +22,7 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned q
     for (int i = 0; i < 16; ++i) u[i] = q * (i + 1);
     asm volatile("v_cmp_gt_u32_e32 vcc, 7, %0\n v_cmp_gt_u32_e64 s[20:21], 9, %0" : : "v"(q) : "vcc", "s20", "s21");
     v2f ab = {a, b};
+    const unsigned long long c_begin = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; ++it) {
         if (OP == 0) {
 #define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
@@ -273,6 +275,8 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned q
 #undef X
         }
     }
+    const unsigned long long c_end = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) cyc[blockIdx.x] = c_end - c_begin;
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += v[i];
     for (int i = 0; i < 8; ++i) s += w[i].x + w[i].y;
@@ -288,23 +292,33 @@ __global__ void k_clock(unsigned long long *out) {
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (unsigned long long)x; }
 }
 
+static unsigned long long *g_cyc = nullptr;
 template <int OP>
 void run(const char *name, int per_iter, float *d, int waves_per_simd) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int blocks = p.multiProcessorCount * 4 * waves_per_simd;
+    if (!g_cyc) hipMalloc(&g_cyc, sizeof(unsigned long long) * 256 * 4 * 8 * 2);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<OP><<<blocks, 64>>>(d, 1.0001f, 0.5f, 0x3c003c00u);
+    k<OP><<<blocks, 64>>>(d, 1.0001f, 0.5f, 0x3c003c00u, g_cyc);
     hipEventRecord(e0);
-    k<OP><<<blocks, 64>>>(d, 1.0001f, 0.5f, 0x3c003c00u);
+    k<OP><<<blocks, 64>>>(d, 1.0001f, 0.5f, 0x3c003c00u, g_cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double clk = (double)p.clockRate * 1e3;  // Hz
+    std::vector<unsigned long long> h(blocks);
+    hipMemcpy(h.data(), g_cyc, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost);
+    double mean_cyc = 0;
+    for (auto c : h) mean_cyc += (double)c;
+    mean_cyc /= blocks;
+    const double clk = (double)p.clockRate * 1e3;  // Hz, nominal
     const double insts_per_simd = (double)ITER * per_iter * waves_per_simd;
-    printf("%-18s waves/SIMD %d : %.3f ms, %.3f wave-inst/cycle/SIMD (clock %.0f MHz)\n", name, waves_per_simd, ms, insts_per_simd / (ms * 1e-3 * clk), clk / 1e6);
+    // two denominators: wall time x the NOMINAL clock (what round 2 quoted), and the shader cycles the waves really saw
+    // (s_memtime): the second is the issue rate, the ratio of the two is the clock the SIMDs ran at under this instruction
+    printf("%-18s waves/SIMD %d : %.3f ms, %.3f wave-inst/cycle/SIMD at the nominal %.0f MHz | %.3f per REAL shader cycle (s_memtime: %.0f cycles per wave => %.0f MHz effective)\n",
+           name, waves_per_simd, ms, insts_per_simd / (ms * 1e-3 * clk), clk / 1e6, insts_per_simd / mean_cyc, mean_cyc, mean_cyc / (ms * 1e-3) / 1e6);
 }
 
 int main() {
