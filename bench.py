@@ -70,6 +70,8 @@ def parse_args(argv=None):
                     help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv) or the dense ncclReduce of the accumulation buffer")
     ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
+    ap.add_argument("--root-weight", type=int, default=0, help="N>1: tile-ownership weight of rank 0 against 8 for every other rank (lpt_renderer_set_shard_weighted): "
+                    "rank 0 also unpacks, resolves and reads back the frame, so it gets fewer tiles; 0 = calibrate in the warm-up, 8 = equal shares")
     ap.add_argument("--eager", action="store_true", help="experiments: every raytrace() launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour)")
     ap.add_argument("--max-fused", type=int, default=0, help="experiments: lpt_renderer_set_max_fused(n) on the timed renderer (0 = the library's default)")
     ap.add_argument("--lanes", type=int, default=0, help="experiments: wavefront lanes of the timed renderer (0 = the library's default)")
@@ -300,6 +302,8 @@ def run(args):
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
 
+    weights = [None]   # tile-ownership weights of the ranks (None = equal shares), the same on every rank
+
     def make_renderer(comm=None, lanes=None):
         rr = lp.Renderer(dev, (WIDTH, HEIGHT))
         if lanes:
@@ -311,7 +315,7 @@ def run(args):
         rr.set_max_bounces(DEPTH)
         rr.set_vfov(T.VFOV)
         if comm is not None:
-            rr.set_comm(comm)                      # = set_shard(rank, world, 32, 8) + the binding
+            rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)
         elif args.emulate_shard > 1:
             rr.set_shard(0, args.emulate_shard, 32, 8)
@@ -348,6 +352,44 @@ def run(args):
         for _ in range(FPS):
             span_frame()
     fence([r])
+    # N>1: rank 0 does more per frame than the others (unpack, resolve, the read-back): give it fewer tiles, so that its frame
+    # takes as long as theirs.  Calibrated here on equal shares: c0 = what a frame costs beyond the slowest rank's tracing.
+    calib = None
+    if world > 1:
+        if args.root_weight:
+            w0 = max(0, min(8, args.root_weight))
+        else:
+            CAL = 10
+            r.enable_timings(True)
+            fence([r])
+            tc = time.perf_counter()
+            for _ in range(CAL):
+                span_frame()
+            fence([r])
+            t_frame = (time.perf_counter() - tc) / CAL * 1e3
+            tm = r.timings()
+            r.enable_timings(False)
+            t_tr = sum(tm.get(k, (0.0, 0))[0] for k in ("ray generation", "intersection", "shading", "shadow", "accumulation")) / CAL
+            tt_ = torch.tensor([t_tr], dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.SUM)
+            t_tr_mean = float(tt_.item()) / world
+            c0 = max(0.0, t_frame - t_tr_mean)
+            share0 = 1.0 - c0 * (world - 1) / max(world * t_tr_mean, 1e-9)      # rank 0's share relative to an equal share
+            w0 = max(1, min(8, int(round(8.0 * share0))))
+            calib = {"frame_ms_equal_shares": t_frame, "trace_ms_mean": t_tr_mean, "rank0_extra_ms": c0, "share0": share0}
+        box = [w0]
+        dist.broadcast_object_list(box, src=0)                                   # every rank uses rank 0's figure
+        w0 = int(box[0])
+        if w0 != 8:
+            weights[0] = [w0] + [8] * (world - 1)
+            r.close()
+            r = make_renderer(comms[0], lanes=args.lanes or None)
+            if args.max_fused:
+                r.set_max_fused(args.max_fused)
+            for _ in range(max(1, args.warmup)):
+                for _ in range(FPS):
+                    span_frame()
+            fence([r])
     r.reset_ray_counts()
     r.enable_timings(True)
     fence([r])
@@ -495,7 +537,10 @@ def run(args):
                 "exchange_frame_complete_on_rank0": frame_ok,
                 "exchange_ms_per_frame_rank0": exchange_ms[0] / max(exchange_ms[1], 1), "exchanges_timed": exchange_ms[1],
                 "exchange_ms_what": "HIP events on rank 0's renderer stream from the pack kernel to the end of the unpack: includes waiting for the slowest rank's tiles",
-                "per_rank_rays": per_rank, "mode": args.exchange}
+                "per_rank_rays": per_rank, "mode": args.exchange,
+                "tile_weights": weights[0] or [1] * world, "tile_weight_calibration": calib,
+                "tile_weights_what": "rank 0 unpacks, resolves and reads back every frame besides tracing: it owns fewer tiles (lpt_renderer_set_shard_weighted), "
+                                     "so that its frame takes as long as the others' — the image does not depend on the weights"}
 
     out = None
     if rank == 0:

@@ -390,6 +390,14 @@ int lpt_renderer_set_vfov(lpt_renderer *r, float radians);
  * ≡ rank (mod world_size).  Default (0,1,32,8) = everything.  The tile area must be a multiple of 64 (one wave). */
 int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world_size, uint32_t tile_w,
                            uint32_t tile_h);
+/* new: the same with WEIGHTED ownership.  Tile t belongs to virtual rank t % V, V = the sum of the weights, and the virtual
+ * ranks are dealt to the ranks in proportion to `weights[rank]` (world_size entries, each 0..8, sum 1..64, at most 32 ranks;
+ * NULL = every rank 1 = the rule above).  A rank that also assembles, reads back or filters the frame (rank 0 of an exchange)
+ * is given a smaller weight so that its frame takes as long as the others': e.g. {5,8,8,8,8,8,8,8}.  A weight of 0 makes a
+ * rank a pure compositor.  Every rank must pass the same weights.  Results do not depend on the weights (the RNG is keyed by
+ * the global pixel): tests/test_gpu_exchange.py. */
+int lpt_renderer_set_shard_weighted(lpt_renderer *r, uint32_t rank, uint32_t world_size, uint32_t tile_w, uint32_t tile_h,
+                                    const uint32_t *weights_or_null);
 /* new (multi-GPU denoising; reference: asvgf passes run on the one GPU, renderer.rs:513-522).  With set_shard(world > 1)
  * and a denoising BlitMode, raytrace() fills only this rank's tiles of the filter inputs.  `lpt_renderer_denoiser_inputs`
  * returns the device pointers of the full-frame input buffers of the CURRENT frame (noisy radiance float4, G-buffer
@@ -445,6 +453,9 @@ enum {
 /* Binds a communicator (NULL unbinds: single-GPU again).  Implies lpt_renderer_set_shard(rank, world, 32, 8) with the
  * communicator's rank / size and therefore resets the accumulation. */
 int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm_or_null);
+/* lpt_renderer_set_comm with weighted tile ownership (lpt_renderer_set_shard_weighted; `weights` has one entry per rank of the
+ * communicator, the same on every rank). */
+int lpt_renderer_set_comm_weighted(lpt_renderer *r, lpt_comm *comm_or_null, const uint32_t *weights_or_null);
 /* Combines the ranks' accumulation buffers into rank 0's PRESENTED frame (a separate full-frame buffer: every rank's own
  * accumulation buffer stays owned-pixels-only, so progressive frames can be exchanged again and again).  Collective over
  * the communicator; asynchronous; a no-op without a communicator.  In the denoising BlitModes it exchanges the filter
@@ -476,6 +487,10 @@ int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
  * outside the image) and where its slots start in the concatenation of all ranks' slot arrays on rank 0. */
 int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world_size, uint32_t rank,
                      uint32_t *out_slots, uint32_t *out_slot_offset);
+int lpt_shard_layout_weighted(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world_size, uint32_t rank,
+                              const uint32_t *weights_or_null, uint32_t *out_slots, uint32_t *out_slot_offset);
+/* the rank that owns tile `tile` (row-major over the tile grid) under the ownership rule (weights NULL = tile % world_size) */
+int lpt_shard_owner(uint32_t world_size, const uint32_t *weights_or_null, uint32_t tile, uint32_t *out_rank);
 int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
 /* per-bounce queue sizes of the LAST traced frame: closest[b] = closest-hit rays of bounce b, shadow[b] = shadow rays
  * emitted by bounce b; up to `cap` entries each (either pointer may be NULL).  Blocking. */

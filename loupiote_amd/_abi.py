@@ -145,6 +145,10 @@ SIGNATURES = {
     "lpt_renderer_exchange": (_i, [_vp, _i]),
     "lpt_renderer_exchange_local": (_i, [_vp, _pvp, _i]),
     "lpt_shard_layout": (_i, [_u32, _u32, _u32, _u32, _u32, _u32, _pu32, _pu32]),
+    "lpt_shard_layout_weighted": (_i, [_u32, _u32, _u32, _u32, _u32, _u32, _vp, _pu32, _pu32]),
+    "lpt_shard_owner": (_i, [_u32, _vp, _u32, _pu32]),
+    "lpt_renderer_set_shard_weighted": (_i, [_vp, _u32, _u32, _u32, _u32, _vp]),
+    "lpt_renderer_set_comm_weighted": (_i, [_vp, _vp, _vp]),
     "lpt_renderer_set_lanes": (_i, [_vp, _i]),
     "lpt_renderer_set_sort_queues": (_i, [_vp, _i]),
     "lpt_renderer_get_queue_counts": (_i, [_vp, _vp, _vp, _u32]),

@@ -419,12 +419,18 @@ class Renderer:
     def set_vfov(self, radians):
         _check(A.lib().lpt_renderer_set_vfov(self._h, float(radians)))
 
-    def set_shard(self, rank, world_size, tile_w=32, tile_h=8):
-        _check(A.lib().lpt_renderer_set_shard(self._h, rank, world_size, tile_w, tile_h))
+    def set_shard(self, rank, world_size, tile_w=32, tile_h=8, weights=None):
+        """this process traces the tiles of `rank`; `weights` (one small integer per rank, the same everywhere) gives ranks unequal
+        shares — e.g. fewer tiles for the rank that also assembles and reads back the frame"""
+        w = None if weights is None else np.ascontiguousarray(weights, np.uint32)
+        if w is not None and w.size != world_size:
+            raise ValueError("weights: one entry per rank")
+        _check(A.lib().lpt_renderer_set_shard_weighted(self._h, rank, world_size, tile_w, tile_h, A.ptr(w)))
 
-    def set_comm(self, comm):
-        """bind a `Comm` (None unbinds); implies set_shard(rank, world, 32, 8)"""
-        _check(A.lib().lpt_renderer_set_comm(self._h, comm._h if comm is not None else None))
+    def set_comm(self, comm, weights=None):
+        """bind a `Comm` (None unbinds); implies set_shard(rank, world, 32, 8, weights)"""
+        w = None if weights is None else np.ascontiguousarray(weights, np.uint32)
+        _check(A.lib().lpt_renderer_set_comm_weighted(self._h, comm._h if comm is not None else None, A.ptr(w)))
 
     def exchange(self, mode=A.EXCHANGE_GATHER_TILES):
         """combine the ranks' frames into rank 0's presented frame (RCCL, asynchronous on the renderer's stream)"""

@@ -176,6 +176,10 @@ struct lpt_renderer {
     uint32_t max_bounces = 3, user_seed = 0;
     float vfov = 0.78539816339744830962f;
     uint32_t rank = 0, world = 1, tile_w = 32, tile_h = 8;
+    std::vector<uint32_t> weights;   // tile-ownership weights of the ranks (empty = every rank 1: tile id mod world)
+    ShardMap map{1u, 1u, {0u}};      // this rank's part of the ownership rule
+    ShardTable h_table{};            // rank 0: the whole rule (staging offsets of the ranks) ...
+    ShardTable *d_table = nullptr;   // ... and its copy in device memory for the unpack kernels; refreshed by alloc_frame_buffers
     bool use_noise = false, stats = false, timings = false;
     // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
     int refill = 44;
@@ -938,12 +942,60 @@ static void free_frame_buffers(lpt_renderer *r) {
     r->n_slots = 0;
 }
 
+// ---- tile ownership (kernels.h ShardMap / ShardTable).  The V = sum(weights) virtual ranks are dealt to the ranks so that every
+// rank's share of any run of tiles follows its weight: virtual rank v goes to the rank that is furthest behind its share
+// (ties: the lowest rank).  Unit weights give virtual rank = rank.  Pure host arithmetic, the same on every rank.
+static std::vector<uint32_t> deal_virtual_ranks(const std::vector<uint32_t> &weights, uint32_t world) {
+    std::vector<uint32_t> owner;
+    if (weights.empty()) { owner.resize(world); for (uint32_t q = 0; q < world; ++q) owner[q] = q; return owner; }
+    uint32_t V = 0;
+    for (uint32_t wq : weights) V += wq;
+    std::vector<uint32_t> given(world, 0u);
+    for (uint32_t v = 0; v < V; ++v) {
+        uint32_t best = 0;
+        long long best_deficit = -(1ll << 60);
+        for (uint32_t q = 0; q < world; ++q) {
+            const long long deficit = (long long)weights[q] * (v + 1u) - (long long)given[q] * V;   // share due - share given, times V
+            if (given[q] < weights[q] && deficit > best_deficit) { best = q; best_deficit = deficit; }
+        }
+        owner.push_back(best);
+        given[best]++;
+    }
+    return owner;
+}
+static inline uint32_t tiles_of_virtual(uint32_t n_tiles, uint32_t V, uint32_t v) { return n_tiles / V + (v < n_tiles % V ? 1u : 0u); }
+static ShardMap make_shard_map(const std::vector<uint32_t> &weights, uint32_t rank, uint32_t world) {
+    ShardMap m{};
+    const std::vector<uint32_t> owner = deal_virtual_ranks(weights, world);
+    m.V = (uint32_t)owner.size();
+    for (uint32_t v = 0; v < m.V; ++v)
+        if (owner[v] == rank && m.w < kMaxWeight) m.vlist[m.w++] = v;
+    return m;
+}
+static uint32_t owned_tiles(const ShardMap &m, uint32_t n_tiles) {
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < m.w; ++j) n += tiles_of_virtual(n_tiles, m.V, m.vlist[j]);
+    return n;
+}
+static ShardTable make_shard_table(const std::vector<uint32_t> &weights, uint32_t world, uint32_t n_tiles, uint32_t area) {
+    ShardTable t{};
+    const std::vector<uint32_t> owner = deal_virtual_ranks(weights, world);
+    t.V = (uint32_t)owner.size();
+    std::vector<uint32_t> tiles(world, 0u);
+    for (uint32_t v = 0; v < t.V; ++v) {
+        t.owner[v] = (uint8_t)owner[v];
+        t.j[v] = (uint8_t)t.w[owner[v]]++;
+        tiles[owner[v]] += tiles_of_virtual(n_tiles, t.V, v);
+    }
+    for (uint32_t q = 0; q < world; ++q) t.offset[q + 1] = t.offset[q] + tiles[q] * area;
+    return t;
+}
+
 static void shard_geometry(const lpt_renderer *r, uint32_t &tiles_x, uint32_t &n_tiles, uint32_t &n_slots) {
     tiles_x = div_up(r->w, r->tile_w);
     const uint32_t tiles_y = div_up(r->h, r->tile_h);
     n_tiles = tiles_x * tiles_y;
-    const uint32_t owned = n_tiles > r->rank ? div_up(n_tiles - r->rank, r->world) : 0u;
-    n_slots = owned * r->tile_w * r->tile_h;
+    n_slots = owned_tiles(r->map, n_tiles) * r->tile_w * r->tile_h;
 }
 
 // per-ray buffers of one lane (queues, hits, shadow queue, per-sample radiance): n_slots * samples elements
@@ -984,6 +1036,11 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     shard_geometry(r, tiles_x, n_tiles, n_slots);
     const size_t px = (size_t)r->w * r->h;
     r->n_slots = n_slots;   // the lanes' ray buffers are allocated by the first raytrace() that uses them
+    if (r->rank == 0u) {   // a possible root of an exchange (also of a one-rank communicator): the whole ownership rule, for the unpack kernels
+        r->h_table = make_shard_table(r->weights, r->world, n_tiles, r->tile_w * r->tile_h);
+        if (!r->d_table) HIP_TRY(hipMalloc(&r->d_table, sizeof(ShardTable)));
+        HIP_TRY(hipMemcpy(r->d_table, &r->h_table, sizeof(ShardTable), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc(&r->accum, sizeof(float4) * px));
     HIP_TRY(hipMalloc(&r->scratch, sizeof(float4) * px));
     HIP_TRY(hipMemsetAsync(r->accum, 0, sizeof(float4) * px, r->stream));
@@ -1055,6 +1112,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
         if (wf.ctr) hipFree(wf.ctr);
     }
     if (r->totals) hipFree(r->totals);
+    if (r->d_table) hipFree(r->d_table);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->srgb_thr) hipFree(r->srgb_thr);
     if (r->xevent) hipEventDestroy(r->xevent);
@@ -1128,13 +1186,31 @@ int lpt_renderer_set_vfov(lpt_renderer *r, float radians) {
     r->vfov = radians;
     return LPT_OK;
 }
-int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h) {
+int lpt_renderer_set_shard_weighted(lpt_renderer *r, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h, const uint32_t *weights) {
     if (!r || world == 0 || rank >= world || tile_w == 0 || tile_h == 0 || (tile_w * tile_h) % 64u != 0u)
         return fail(LPT_ERR_INVALID_ARG, "bad shard (rank %u of %u, tile %ux%u; tile area must be a multiple of 64)", rank, world, tile_w, tile_h);
+    std::vector<uint32_t> wv;
+    if (weights) {
+        if (world > kMaxWorld) return fail(LPT_ERR_INVALID_ARG, "weighted shards: at most %u ranks", kMaxWorld);
+        uint32_t sum = 0;
+        bool unit = true;
+        for (uint32_t q = 0; q < world; ++q) {
+            if (weights[q] > kMaxWeight) return fail(LPT_ERR_INVALID_ARG, "weighted shards: weight %u of rank %u exceeds %u", weights[q], q, kMaxWeight);
+            sum += weights[q];
+            unit = unit && weights[q] == 1u;
+        }
+        if (sum == 0u || sum > kMaxVirtual) return fail(LPT_ERR_INVALID_ARG, "weighted shards: the weights must sum to 1..%u (got %u)", kMaxVirtual, sum);
+        if (!unit) wv.assign(weights, weights + world);
+    }
     FLUSH_OR_RETURN(r);
     r->rank = rank; r->world = world; r->tile_w = tile_w; r->tile_h = tile_h;
+    r->weights = wv;
+    r->map = make_shard_map(r->weights, rank, world);
     r->frame_count = 1;
     return alloc_frame_buffers(r);
+}
+int lpt_renderer_set_shard(lpt_renderer *r, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h) {
+    return lpt_renderer_set_shard_weighted(r, rank, world, tile_w, tile_h, nullptr);
 }
 int lpt_renderer_reset_accumulation(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_reset_accumulation: null");
@@ -1302,6 +1378,7 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
     p.user_seed = r->user_seed;
     p.seed_counter = seed0;
     p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
+    p.map = r->map;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
     p.frame_count = frame_count0;
     p.max_bounces = nb;
@@ -1747,24 +1824,53 @@ int lpt_comm_info(const lpt_comm *c, int *rank, int *world) {
     return LPT_OK;
 }
 
-int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, uint32_t *out_slots, uint32_t *out_offset) {
+int lpt_shard_layout_weighted(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, const uint32_t *weights,
+                              uint32_t *out_slots, uint32_t *out_offset) {
     if (!world || rank >= world || !tile_w || !tile_h) return fail(LPT_ERR_INVALID_ARG, "lpt_shard_layout: bad shard (rank %u of %u, tile %ux%u)", rank, world, tile_w, tile_h);
     const uint32_t n_tiles = div_up(width, tile_w) * div_up(height, tile_h), area = tile_w * tile_h;
-    const uint32_t a = shard_slot_offset(n_tiles, world, area, rank), b = shard_slot_offset(n_tiles, world, area, rank + 1u);
-    if (out_slots) *out_slots = b - a;
-    if (out_offset) *out_offset = a;
+    if (!weights) {   // unit weights: the closed form (any world size)
+        const uint32_t a = shard_slot_offset(n_tiles, world, area, rank), b = shard_slot_offset(n_tiles, world, area, rank + 1u);
+        if (out_slots) *out_slots = b - a;
+        if (out_offset) *out_offset = a;
+        return LPT_OK;
+    }
+    if (world > kMaxWorld) return fail(LPT_ERR_INVALID_ARG, "weighted shards: at most %u ranks", kMaxWorld);
+    uint32_t sum = 0;
+    for (uint32_t q = 0; q < world; ++q) { if (weights[q] > kMaxWeight) return fail(LPT_ERR_INVALID_ARG, "weighted shards: weight %u exceeds %u", weights[q], kMaxWeight); sum += weights[q]; }
+    if (sum == 0u || sum > kMaxVirtual) return fail(LPT_ERR_INVALID_ARG, "weighted shards: the weights must sum to 1..%u (got %u)", kMaxVirtual, sum);
+    const ShardTable t = make_shard_table(std::vector<uint32_t>(weights, weights + world), world, n_tiles, area);
+    if (out_slots) *out_slots = t.offset[rank + 1] - t.offset[rank];
+    if (out_offset) *out_offset = t.offset[rank];
+    return LPT_OK;
+}
+int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, uint32_t *out_slots, uint32_t *out_offset) {
+    return lpt_shard_layout_weighted(width, height, tile_w, tile_h, world, rank, nullptr, out_slots, out_offset);
+}
+// which rank owns tile `tile` (row-major over the tile grid) under the rule above: for hosts and tests that check the layout
+int lpt_shard_owner(uint32_t world, const uint32_t *weights, uint32_t tile, uint32_t *out_rank) {
+    if (!world || !out_rank || (weights && world > kMaxWorld)) return fail(LPT_ERR_INVALID_ARG, "lpt_shard_owner: bad arguments");
+    std::vector<uint32_t> wv;
+    if (weights) {
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < world; ++q) { if (weights[q] > kMaxWeight) return fail(LPT_ERR_INVALID_ARG, "weighted shards: weight %u exceeds %u", weights[q], kMaxWeight); sum += weights[q]; }
+        if (sum == 0u || sum > kMaxVirtual) return fail(LPT_ERR_INVALID_ARG, "weighted shards: the weights must sum to 1..%u (got %u)", kMaxVirtual, sum);
+        wv.assign(weights, weights + world);
+    }
+    const std::vector<uint32_t> owner = deal_virtual_ranks(wv, world);
+    *out_rank = owner[tile % owner.size()];
     return LPT_OK;
 }
 
-int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm) {
+int lpt_renderer_set_comm_weighted(lpt_renderer *r, lpt_comm *comm, const uint32_t *weights) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: null");
     if (comm && comm->dev != r->dev) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_comm: the communicator belongs to another device");
     FLUSH_OR_RETURN(r);
     // bind only once the shard is in place: a failed set_shard must not leave a half-bound renderer
-    const int st = comm ? lpt_renderer_set_shard(r, (uint32_t)comm->rank, (uint32_t)comm->world, 32u, 8u) : lpt_renderer_set_shard(r, 0u, 1u, 32u, 8u);
+    const int st = comm ? lpt_renderer_set_shard_weighted(r, (uint32_t)comm->rank, (uint32_t)comm->world, 32u, 8u, weights) : lpt_renderer_set_shard(r, 0u, 1u, 32u, 8u);
     if (st == LPT_OK) r->comm = comm;
     return st;
 }
+int lpt_renderer_set_comm(lpt_renderer *r, lpt_comm *comm) { return lpt_renderer_set_comm_weighted(r, comm, nullptr); }
 
 }  // extern "C"
 
@@ -1773,12 +1879,11 @@ static FrameParams shard_params(const lpt_renderer *r) {
     FrameParams p{};
     p.width = r->w; p.height = r->h;
     p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
+    p.map = r->map;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
     return p;
 }
-static uint32_t slots_of_rank(const FrameParams &p, uint32_t q) {
-    return shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q + 1u) - shard_slot_offset(p.n_tiles, p.world, p.tile_w * p.tile_h, q);
-}
+
 // `frame` (the presented whole frame: only where it is written — the root, or every rank of a reduce, which needs a valid
 // receive buffer) and the staging area for packed tiles: this rank's slots, or every rank's on the root
 static int ensure_exchange_buffers(lpt_renderer *r, bool root, bool want_frame, bool want_stage, size_t bytes_per_slot = 16) {
@@ -1825,16 +1930,15 @@ static int exchange_enqueue(lpt_renderer *r, int mode) {
         int st = ensure_exchange_buffers(r, root, false, true, 40);
         if (st != LPT_OK) return st;
         const FrameParams p = shard_params(r);
-        const uint32_t area = p.tile_w * p.tile_h;
         unsigned char *stage = reinterpret_cast<unsigned char *>(r->xstage);
         if (p.n_slots) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion, stage);
         HIP_TRY(hipGetLastError());
         if (root) {
             RCCL_TRY(nc.GroupStart());
             for (uint32_t q = 1; q < p.world; ++q) {
-                const uint32_t nq = slots_of_rank(p, q);
+                const uint32_t nq = r->h_table.offset[q + 1] - r->h_table.offset[q];
                 if (!nq) continue;
-                ncclResult_t e = nc.Recv(stage + 40u * (size_t)shard_slot_offset(p.n_tiles, p.world, area, q), 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
+                ncclResult_t e = nc.Recv(stage + 40u * (size_t)r->h_table.offset[q], 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
                 if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
             }
             RCCL_TRY(nc.GroupEnd());
@@ -1851,15 +1955,14 @@ static int exchange_enqueue(lpt_renderer *r, int mode) {
         RCCL_TRY(nc.Reduce(r->accum, r->frame, 4 * npx, ncclFloat32, ncclSum, 0, c->comm, s));
         return LPT_OK;
     }
-    const uint32_t area = p.tile_w * p.tile_h;
     if (p.n_slots) hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, s, p, r->accum, r->xstage);   // rank 0's offset is 0
     HIP_TRY(hipGetLastError());
     if (root) {
         RCCL_TRY(nc.GroupStart());
         for (uint32_t q = 1; q < p.world; ++q) {
-            const uint32_t nq = slots_of_rank(p, q);
+            const uint32_t nq = r->h_table.offset[q + 1] - r->h_table.offset[q];
             if (!nq) continue;
-            ncclResult_t e = nc.Recv(r->xstage + shard_slot_offset(p.n_tiles, p.world, area, q), 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
+            ncclResult_t e = nc.Recv(r->xstage + r->h_table.offset[q], 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
             if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
         }
         RCCL_TRY(nc.GroupEnd());
@@ -1877,7 +1980,7 @@ static int exchange_finish(lpt_renderer *r, int mode) {
     if (r->mode != LPT_BLIT_PATHTRACE) {
         if (root && mode == LPT_EXCHANGE_GATHER_TILES) {
             const FrameParams p = shard_params(r);
-            hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, reinterpret_cast<unsigned char *>(r->xstage), r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
+            hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->d_table, reinterpret_cast<unsigned char *>(r->xstage), r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
         }
         if (root && r->world != 1u) launch_filter(r, s);   // world == 1: raytrace() has filtered already
         HIP_TRY(hipGetLastError());
@@ -1887,7 +1990,7 @@ static int exchange_finish(lpt_renderer *r, int mode) {
     }
     if (root && mode == LPT_EXCHANGE_GATHER_TILES) {
         const FrameParams p = shard_params(r);
-        hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->xstage, r->frame);
+        hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->d_table, r->xstage, r->frame);
         HIP_TRY(hipGetLastError());
     }
     stage_end(r, s);
@@ -1963,7 +2066,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     for (int i = 0; i < n_peers; ++i) {
         const lpt_renderer *q = peers[i];
         if (!q || q->w != root->w || q->h != root->h || q->world != root->world || q->tile_w != root->tile_w || q->tile_h != root->tile_h || q->rank >= root->world || seen[q->rank] ||
-            (q->mode != LPT_BLIT_PATHTRACE) != den)
+            q->weights != root->weights || (q->mode != LPT_BLIT_PATHTRACE) != den)
             return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: peer %d does not complete the shard set of the root", i);
         if (den && (!q->den_temp || !q->den_inputs_ready)) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_exchange_local: peer %d has not traced a denoising frame", i);
         seen[q->rank] = 1;
@@ -1974,7 +2077,6 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
     int st = ensure_exchange_buffers(root, true, true, true, bps);
     if (st != LPT_OK) return st;
     const FrameParams p0 = shard_params(root);
-    const uint32_t area = p0.tile_w * p0.tile_h;
     unsigned char *stage0 = reinterpret_cast<unsigned char *>(root->xstage);
     if (p0.n_slots) {
         if (den) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(root, p0.n_slots)), dim3(kBlock), 0, root->stream, p0, root->den_noisy, root->den_gbuf[root->den_cur], root->den_motion, stage0);
@@ -1992,7 +2094,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
             if (den) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->den_noisy, q->den_gbuf[q->den_cur], q->den_motion, reinterpret_cast<unsigned char *>(q->xstage));
             else hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->accum, q->xstage);
             // the stand-in of ncclSend / ncclRecv inside one process: a (peer) copy into the root's staging area
-            HIP_TRY(hipMemcpyPeerAsync(stage0 + bps * (size_t)shard_slot_offset(pq.n_tiles, pq.world, area, pq.rank), root->dev->ordinal, q->xstage, q->dev->ordinal,
+            HIP_TRY(hipMemcpyPeerAsync(stage0 + bps * (size_t)root->h_table.offset[pq.rank], root->dev->ordinal, q->xstage, q->dev->ordinal,
                                        bps * (size_t)pq.n_slots, q->stream));
         }
         if (den) q->den_inputs_ready = false;
@@ -2001,7 +2103,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
         HIP_TRY(hipStreamWaitEvent(root->stream, q->xevent, 0));
     }
     if (den) {
-        hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, stage0, root->den_noisy, root->den_gbuf[root->den_cur], root->den_motion);
+        hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, root->d_table, stage0, root->den_noisy, root->den_gbuf[root->den_cur], root->den_motion);
         launch_filter(root, root->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(root->xevent, root->stream));
@@ -2009,7 +2111,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
         root->den_inputs_ready = false;
         return LPT_OK;   // the composite has written the local target
     }
-    hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, root->xstage, root->frame);
+    hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(root, (size_t)root->w * root->h)), dim3(kBlock), 0, root->stream, p0, root->d_table, root->xstage, root->frame);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(root->xevent, root->stream));
     root->xevent_recorded = true;

@@ -76,11 +76,30 @@ struct FrameCounters {
 };
 struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes; };
 
+// Tile ownership.  Tile t (row-major over the tile grid) belongs to VIRTUAL rank t % V; the V virtual ranks are dealt to
+// the ranks in proportion to their weights (a rank that also assembles, reads back or filters the frame gets fewer tiles).  With
+// every weight 1 this is V = world, virtual rank = rank: the plain "tile id mod N" rule.
+constexpr uint32_t kMaxVirtual = 64, kMaxWorld = 32, kMaxWeight = 8;
+struct ShardMap {
+    uint32_t V;                   // virtual ranks = the sum of the weights
+    uint32_t w;                   // this rank's weight = the number of virtual ranks it holds
+    uint32_t vlist[kMaxWeight];   // ... which ones, ascending
+};
+// rank 0's view of the same rule, for the unpack kernels: virtual rank -> (owner, position in the owner's list), and where
+// every rank's slots start in the staging area
+struct ShardTable {
+    uint32_t V;
+    uint8_t owner[kMaxVirtual], j[kMaxVirtual];
+    uint32_t w[kMaxWorld];
+    uint32_t offset[kMaxWorld + 1];   // in slots; offset[world] = all slots
+};
+
 struct FrameParams {
     f3 origin, right, up, fwd;
     float ax, ay;
     uint32_t width, height;
     uint32_t user_seed, seed_counter;
+    ShardMap map;
     uint32_t rank, world, tile_w, tile_h, tiles_x, n_tiles, n_slots;
     uint32_t frame_count, max_bounces;
     // batched samples (lpt_renderer_raytrace_n): sample k of the batch behaves like the k-th of n
@@ -95,12 +114,20 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_nt(const float4 *p) { const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void st_nt(float4 *p, const float4 v) { const f4v w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(p)); }
 
-// pixel slot -> pixel.  Slots enumerate this rank's tiles (tile ids rank, rank+world, ...)
-// and the pixels inside each tile row-major, so a wave64 covers a 32x2 pixel block.
+// pixel slot -> pixel.  Slots enumerate this rank's tiles in ascending tile id (period after period of V tiles, the rank's
+// virtual ranks inside a period; with unit weights: tile ids rank, rank+world, ...) and the pixels inside each tile row-major,
+// so a wave64 covers a 32x2 pixel block.
 __device__ __forceinline__ bool slot_to_pixel(const FrameParams &p, uint32_t slot, uint32_t &x, uint32_t &y) {
     const uint32_t per_tile = p.tile_w * p.tile_h;
     const uint32_t k = slot / per_tile, within = slot - k * per_tile;
-    const uint32_t tile = p.rank + k * p.world;
+    uint32_t period = k, v = p.map.vlist[0];
+    if (p.map.w != 1u) {   // wave-uniform
+        period = k / p.map.w;
+        const uint32_t j = k - period * p.map.w;
+#pragma unroll
+        for (uint32_t q = 1; q < kMaxWeight; ++q) v = j == q ? p.map.vlist[q] : v;   // a select chain: the list lives in SGPRs
+    }
+    const uint32_t tile = period * p.map.V + v;
     if (tile >= p.n_tiles) return false;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const uint32_t wy = within / p.tile_w, wx = within - wy * p.tile_w;
@@ -1037,17 +1064,24 @@ __device__ __host__ __forceinline__ uint32_t shard_slot_offset(uint32_t n_tiles,
     const uint32_t base = n_tiles / world, rem = n_tiles - base * world;
     return (q * base + (q < rem ? q : rem)) * tile_area;
 }
-// rank 0: the whole frame from the concatenated slot arrays (inverse of slot_to_pixel for every owner)
-__global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const float4 *staged, float4 *frame) {
+// tile -> (owner, slot of the tile's first pixel in the owner's slot array): the inverse of slot_to_pixel for every owner
+__device__ __forceinline__ void tile_owner(const ShardTable &t, uint32_t tile, uint32_t area, uint32_t &owner, uint32_t &slot0) {
+    const uint32_t period = tile / t.V, v = tile - period * t.V;
+    owner = t.owner[v];
+    slot0 = (period * t.w[owner] + t.j[v]) * area;
+}
+// rank 0: the whole frame from the concatenated slot arrays
+__global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const ShardTable *tp, const float4 *staged, float4 *frame) {
+    const ShardTable &st = *tp;   // 400 bytes in device memory, read per lane (L1-resident)
     const uint32_t stride = gridDim.x * blockDim.x, npx = p.width * p.height;
     const uint32_t area = p.tile_w * p.tile_h;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
         const uint32_t y = i / p.width, x = i - y * p.width;
         const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
-        const uint32_t tile = ty * p.tiles_x + tx;
-        const uint32_t owner = tile % p.world, k = tile / p.world;
-        const uint32_t slot = k * area + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
-        frame[i] = staged[(size_t)shard_slot_offset(p.n_tiles, p.world, area, owner) + slot];
+        uint32_t owner, slot0;
+        tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
+        const uint32_t slot = slot0 + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        frame[i] = staged[(size_t)st.offset[owner] + slot];
     }
 }
 
@@ -1067,17 +1101,18 @@ __global__ __launch_bounds__(kBlock) void k_pack_den(FrameParams p, const float4
         oc[slot] = in ? motion[px] : make_float2(0.f, 0.f);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_unpack_den(FrameParams p, const unsigned char *staged, float4 *noisy, uint4 *gbuf, float2 *motion) {
+__global__ __launch_bounds__(kBlock) void k_unpack_den(FrameParams p, const ShardTable *tp, const unsigned char *staged, float4 *noisy, uint4 *gbuf, float2 *motion) {
+    const ShardTable &st = *tp;
     const uint32_t stride = gridDim.x * blockDim.x, npx = p.width * p.height;
     const uint32_t area = p.tile_w * p.tile_h;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride) {
         const uint32_t y = i / p.width, x = i - y * p.width;
         const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
-        const uint32_t tile = ty * p.tiles_x + tx;
-        const uint32_t owner = tile % p.world, k = tile / p.world;
-        const uint32_t slot = k * area + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
-        const uint32_t first = shard_slot_offset(p.n_tiles, p.world, area, owner);
-        const size_t n_owner = shard_slot_offset(p.n_tiles, p.world, area, owner + 1u) - first;
+        uint32_t owner, slot0;
+        tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
+        const uint32_t slot = slot0 + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        const uint32_t first = st.offset[owner];
+        const size_t n_owner = st.offset[owner + 1u] - first;
         const unsigned char *base = staged + 40u * (size_t)first;
         noisy[i] = reinterpret_cast<const float4 *>(base)[slot];
         gbuf[i] = reinterpret_cast<const uint4 *>(base + 16u * n_owner)[slot];

@@ -28,14 +28,14 @@ def _setup(device, glb):
     return sg, pr
 
 
-def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8)):
+def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8), weights=None):
     r = lp.Renderer(device, (w, h))
     r.downsample_factor = 1.0
     r.resize(device, sg, pr, (w, h))
     r.set_max_bounces(bounces)
     r.set_vfov(T.VFOV)
     if world > 1:
-        r.set_shard(rank, world, tile[0], tile[1])
+        r.set_shard(rank, world, tile[0], tile[1], weights=weights)
         r.set_resources(device, sg, pr)
     r.reset_accumulation()
     r.accumulate = True
@@ -96,6 +96,51 @@ def test_denoising_modes_exchange_owned_tiles_of_the_filter_inputs(device, corne
             assert got.tobytes() == want.tobytes()
     with pytest.raises(lp.Error):
         ranks[0].exchange_local(ranks[1:])           # the inputs of this frame have been consumed
+    for r in ranks + [one]:
+        r.close()
+    pr.close()
+    sg.close()
+
+
+@pytest.mark.parametrize("w,h,tile,weights,mode", [
+    (200, 120, (32, 8), (1, 3, 2), lp.BlitMode.Pahtrace),
+    (203, 117, (8, 8), (5, 8, 8, 8), lp.BlitMode.Pahtrace),
+    (97, 61, (16, 8), (0, 2, 2, 1), lp.BlitMode.Pahtrace),                # rank 0 owns nothing: a pure compositor
+    (203, 117, (32, 8), (2, 8, 7), lp.BlitMode.DenoisedPathrace),
+    (64, 64, (32, 8), (3, 8, 8, 8, 8, 8, 8, 8), lp.BlitMode.Temporal),
+])
+def test_weighted_tile_ownership_does_not_change_a_bit(device, cornell_glb, w, h, tile, weights, mode):
+    """lpt_renderer_set_shard_weighted: ranks own tiles in proportion to their weights (rank 0, which also unpacks, reads back or
+    filters the frame, gets fewer) — the RNG is keyed by the global pixel, so the exchanged frame equals the single-GPU frame bit
+    for bit, frame after frame, path tracing and denoising; the ranks' work follows the weights"""
+    sg, pr = _setup(device, cornell_glb)
+    world = len(weights)
+    one = _renderer(device, sg, pr, w, h, 4)
+    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, tile, weights) for q in range(world)]
+    den = mode != lp.BlitMode.Pahtrace
+    for r in [one] + ranks:
+        r.set_blit_mode(mode)
+        r.reset_accumulation()
+        r.accumulate = not den
+        r.reset_ray_counts()
+    for f in range(3):
+        view = T.look((0.15 * f, 0.6, 13.5 - 0.2 * f), T.CORNELL_DIR) if den else T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+        one.raytrace(view)
+        for r in ranks:
+            r.raytrace(view)
+        ranks[0].exchange_local(ranks[1:])
+        assert ranks[0].read_radiance().tobytes() == one.read_radiance().tobytes(), "frame %d" % f
+        if den:
+            for got, want in zip(ranks[0].read_denoiser(), one.read_denoiser()):
+                assert got.tobytes() == want.tobytes()
+    counts = [r.ray_counts().closest for r in ranks]
+    assert sum(counts) == one.ray_counts().closest
+    assert all((c == 0) == (wq == 0) for c, wq in zip(counts, weights))
+    # a peer with other weights does not complete the shard set
+    other = _renderer(device, sg, pr, w, h, 4, 1, world, tile, None)
+    with pytest.raises(lp.Error):
+        ranks[0].exchange_local([other] + ranks[2:])
+    other.close()
     for r in ranks + [one]:
         r.close()
     pr.close()
