@@ -393,12 +393,17 @@ def run(args):
     r.reset_ray_counts()
     r.enable_timings(True)
     fence([r])
+    frame_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for _ in range(FPS):
+            tf = time.perf_counter()
             span_frame()
+            frame_ms.append((time.perf_counter() - tf) * 1e3)
     fence([r])
     elapsed = time.perf_counter() - t0
+    slowest_frame = max(range(len(frame_ms)), key=lambda i: frame_ms[i]) if frame_ms else -1
+    frame_ms.sort()
     timings = r.timings()
     r.enable_timings(False)
     c_ = r.ray_counts()
@@ -452,10 +457,39 @@ def run(args):
         byts = (cl * b_ray + sh * b_sh) / max(launches, 1)
         return avg, launches, byts, (byts / (avg * 1e-3) / 1e9 if avg > 0 else 0.0)
 
-    # the timed region runs one frame at a time on one renderer: its launches ARE the un-overlapped launches
-    s_avg, s_launches, s_bytes, s_achieved = trace_stage(timings, closest_l, shadow_l)
-    rays_per_launch = (closest_l + shadow_l) / max(s_launches, 1)
+    # In the timed region the 4 samples of a frame leave as two wavefronts on the renderer's two lanes and overlap: a launch there
+    # shares the chip.  The kernel figure (roofline.frac) is taken from SOLO_FRAMES frames issued as ONE wavefront each
+    # (lpt_renderer_set_max_fused(spp)), one frame at a time: un-overlapped launches, HIP events on the stream they run on.
+    SOLO_FRAMES = 3
+    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l, shadow_l)
+    r.set_max_fused(max(SPP, 1))
+    span_frame()                       # the lanes' ray buffers grow to the batch size on first use
+    fence([r])
+    r.reset_ray_counts()
+    r.enable_timings(True)
+    for _ in range(SOLO_FRAMES):
+        span_frame()
+    fence([r])
+    solo_t = r.timings()
+    r.enable_timings(False)
+    sc_ = r.ray_counts()
+    r.set_max_fused(args.max_fused)
+    s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest, sc_.shadow)
+    rays_per_launch = (sc_.closest + sc_.shadow) / max(s_launches, 1)
     exchange_ms = timings.get("exchange", (0.0, 0))
+
+    # ---- the read-back alone: k_resolve + 33 MB device -> host of an already finished frame (depends on the box's PCIe link and host)
+    readback = None
+    if rank == 0:
+        rb = []
+        for _ in range(8):
+            r.synchronize()
+            t1 = time.perf_counter()
+            r.read_radiance(out=dst)
+            rb.append((time.perf_counter() - t1) * 1e3)
+        rb.sort()
+        readback = {"median_ms": rb[len(rb) // 2], "min_ms": rb[0], "bytes": WIDTH * HEIGHT * 16, "GBps": WIDTH * HEIGHT * 16 / (rb[len(rb) // 2] * 1e-3) / 1e9,
+                    "destination": "pageable" if args.pageable else "page-locked (lpt_host_alloc)"}
 
     # ---- latency: one frame alone, host call to completion, no read-back
     latency = None
@@ -570,15 +604,23 @@ def run(args):
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum},
             "ms_per_frame": elapsed / n_frames * 1e3,
+            "frame_ms_percentiles": {"min": frame_ms[0], "p10": frame_ms[len(frame_ms) // 10], "median": frame_ms[len(frame_ms) // 2],
+                                     "p90": frame_ms[(9 * len(frame_ms)) // 10], "max": frame_ms[-1], "index_of_max": slowest_frame,
+                                     "what": "host wall time of each timed frame on rank 0 (reset ... read_radiance returns)"},
             "throughput": throughput,
             "latency_ms": latency,
+            "readback": readback,
             "rccl": rccl,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": s_achieved / HBM_PEAK_GBS,
                          "traffic": traffic_j.get("k_trace_bytes_per_launch"), "traffic_source": traffic_j.get("source"),
                          "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": s_bytes,
-                         "basis": "the timed region itself: one frame at a time on one renderer, HIP events on the stream the kernel runs on around every k_trace launch — "
-                                  "the duration rocprofv3's kernel trace reports for the same command (profiles/)",
+                         "basis": "un-overlapped launches: %d frames issued as one 4-sample wavefront each (lpt_renderer_set_max_fused(4)), one frame at a time, HIP events on the "
+                                  "stream the kernel runs on around every k_trace launch — the duration rocprofv3's kernel trace reports for `bench.py --max-fused 4 --lanes 1` "
+                                  "(profiles/*_solo_kernel_stats.csv)" % SOLO_FRAMES,
+                         "timed_region": {"achieved": o_achieved, "frac": o_achieved / HBM_PEAK_GBS, "avg_launch_ms": o_avg, "launches": o_launches, "bytes_per_launch": o_bytes,
+                                          "note": "the same over the timed region, where the two 2-sample wavefronts of a frame overlap on the renderer's lanes: a launch shares "
+                                                  "the chip with the other wavefront's kernels — a scheduling figure, not a kernel figure"},
                          "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
                                     "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation, the read-back): a lower bound"},
                          "limits": limits_j,
@@ -591,6 +633,7 @@ def run(args):
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
             "stage_ms_per_frame": {k: v[0] / n_frames for k, v in timings.items()},
+            "stage_ms_per_frame_solo": {k: v[0] / SOLO_FRAMES for k, v in solo_t.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
         }

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 SIMDS = 256 * 4
-FAST_RATE, SLOW_RATE = 0.39, 0.23   # wave-instructions per cycle per SIMD (valu_rate.hip)
+FAST_RATE, SLOW_RATE = 0.40, 0.234  # wave-instructions per REAL shader cycle per SIMD at 8 waves/SIMD (valu_rate under rocprofv3: profiles/r03_valu_rate_real_clock.txt)
 FAST_SHARE = 0.36                   # of k_trace's VALU instructions (85 fast + 150 slow per node visit)
 GATHER_TBS = (9.7, 13.5)
 
@@ -93,9 +93,21 @@ def main(tag, out):
             lim["gather_path"] = {"tb_per_s": tbs, "frac_of_13.5": tbs / GATHER_TBS[1], "frac_of_9.7": tbs / GATHER_TBS[0], "ceiling_tb_per_s": list(GATHER_TBS)}
         if "k_trace_bytes_per_launch" in traffic:
             lim["fabric"] = {"bytes_per_launch": traffic["k_trace_bytes_per_launch"], "frac": traffic["k_trace_bytes_per_launch"] / (avg_ns * 1e-9) / 8e12}
+    # lane efficiency: of the lane slots of the VALU instructions issued, how many carried a live lane (tracked)
+    tc, vi = per_launch(k, "SQ_THREAD_CYCLES_VALU"), per_launch(k, "SQ_INSTS_VALU")
+    if tc and vi:
+        lim["lane_efficiency"] = {"k_trace": tc / (64.0 * vi), "what": "SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)"}
+        tcs, vis = per_launch("k_shade<false>", "SQ_THREAD_CYCLES_VALU"), per_launch("k_shade<false>", "SQ_INSTS_VALU")
+        if tcs and vis:
+            lim["lane_efficiency"]["k_shade"] = tcs / (64.0 * vis)
     h, m = per_launch(k, "TCC_HIT_sum"), per_launch(k, "TCC_MISS_sum")
     if h is not None and m is not None and h + m > 0:
         lim["tcc_hit"] = h / (h + m)
+    # k_shade against the HBM roof: it is the kernel that IS bound by fabric bytes
+    ks = solo.get("k_shade<false>", (None, 0))[0]
+    if ks and "k_shade_bytes_per_launch" in traffic:
+        tb = traffic["k_shade_bytes_per_launch"] / (ks * 1e-9) / 1e12
+        lim["k_shade_fabric"] = {"bytes_per_launch": traffic["k_shade_bytes_per_launch"], "avg_launch_ms": ks / 1e6, "tb_per_s": tb, "frac_of_8": tb / 8.0, "frac_of_6.29_achievable": tb / 6.29}
     k2 = "k_shade<false>"
     h, m = per_launch(k2, "TCC_HIT_sum"), per_launch(k2, "TCC_MISS_sum")
     if h is not None and m is not None and h + m > 0:
@@ -118,7 +130,7 @@ def main(tag, out):
         lim["frame_valu"] = {"valu_wave_insts_per_frame": insts, "k_trace_share": 9.0 * vt / insts, "bound_ms_per_frame": bound_ms,
                              "measured_ms_per_frame": b2["ms_per_frame"], "frac": bound_ms / b2["ms_per_frame"], "clock_hz": clock,
                              "note": "all VALU wave-instructions of a frame (9 k_trace + 8 k_shade launches) at the issue ceiling of k_trace's mix vs the "
-                                     "measured throughput interval (three frames in flight): the frame as a whole is VALU-issue bound"}
+                                     "measured frame (the SURVEY 8d span: one renderer, read-back included)"}
     wv, wc, bc = per_launch(k, "SQ_WAVES"), per_launch(k, "SQ_WAVE_CYCLES"), per_launch(k, "SQ_BUSY_CYCLES")
     if wv:
         lim["waves_per_launch"] = wv
