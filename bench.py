@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the throughput / latency measurements (experiments)")
+    ap.add_argument("--throughput", action="store_true", help="N>1: also run the frames-in-flight leg (several renderers, one RCCL communicator each); on one GPU it always runs")
     ap.add_argument("--width", type=int, default=WIDTH, help="experiments only; the reported config is the default")
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP)
@@ -285,11 +286,14 @@ def run(args):
     dev = lp.Device(local_rank)
     P = args.pipeline if args.pipeline > 0 else (4 if (world > 1 or args.emulate_shard > 1) else 3)
     extras = not args.no_extras
+    # frames in flight over several communicators has never run on more than one GPU: on N>1 it is opt-in, so that an
+    # untested leg cannot take the headline measurement down with it
+    tp_leg = extras and (world == 1 or args.throughput)
     comms = []
     if use_dist:
         # one communicator for the timed renderer + one per pipelined renderer of the throughput measurement: RCCL serialises
         # the operations of ONE communicator, so frames in flight must not share one
-        n_comms = 1 + (P if extras else 0)
+        n_comms = 1 + (P if tp_leg else 0)
         box = [[lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         for uid in box[0]:
@@ -513,7 +517,7 @@ def run(args):
 
     # ================================================================== throughput: P renderers in flight, batched samples, no read-back
     throughput = None
-    if extras:
+    if tp_leg:
         rs = [make_renderer(comms[1 + k] if comms else None, lanes=1) for k in range(P)]
         T_STEPS = max(2, min(args.steps, 6))
         no = [0]

@@ -212,6 +212,7 @@ struct lpt_renderer {
     float2 *den_motion = nullptr;
     float4 *den_temp = nullptr;
     float4 *den_noisy = nullptr;  // per-pixel sample radiance of the current frame (filter input; exchanged when sharded)
+    float4 *den_nd = nullptr;     // the current G-buffer's normal + depth, decoded once per frame for the a-trous passes
     bool den_inputs_ready = false;
     int den_cur = 1;              // current_frame_back starts true (asvgf.rs:233); start() flips it
     CamBasis prev_cam{};          // prev_model_to_screen (renderer.rs:201,319,542-546), identity at start
@@ -891,7 +892,8 @@ static void free_denoiser(lpt_renderer *r) {
     if (r->den_motion) hipFree(r->den_motion);
     if (r->den_temp) hipFree(r->den_temp);
     if (r->den_noisy) hipFree(r->den_noisy);
-    r->den_motion = nullptr; r->den_temp = nullptr; r->den_noisy = nullptr;
+    if (r->den_nd) hipFree(r->den_nd);
+    r->den_motion = nullptr; r->den_temp = nullptr; r->den_noisy = nullptr; r->den_nd = nullptr;
     r->den_inputs_ready = false;
     r->den_cur = 1;
 }
@@ -913,6 +915,7 @@ static int ensure_denoiser(lpt_renderer *r) {
     HIP_TRY(hipMalloc(&r->den_motion, sizeof(float2) * n));
     HIP_TRY(hipMalloc(&r->den_temp, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&r->den_noisy, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->den_nd, sizeof(float4) * n));
     HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * n, s));
     HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * n, s));
     HIP_TRY(hipStreamSynchronize(s));   // the primary pass of the first frame may run on a lane's stream
@@ -1348,10 +1351,11 @@ static void launch_filter(lpt_renderer *r, hipStream_t s) {
     if (r->mode == LPT_BLIT_DENOISED) {
         hipMemcpyAsync(r->den_temp, r->den_rad[cur], sizeof(float4) * npx, hipMemcpyDeviceToDevice, s);  // copy_texture_to_texture
         // even number of a-trous calls: main <-> radiance_temp, result ends in radiance_temp (asvgf.rs:286-287)
-        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 1);
-        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 2);
-        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_temp, r->accum, (int)r->w, (int)r->h, 4);
-        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->accum, r->den_temp, (int)r->w, (int)r->h, 8);
+        hipLaunchKernelGGL(k_decode_gbuf, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], r->den_nd, npx);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_nd, r->den_temp, r->accum, (int)r->w, (int)r->h, 1);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_nd, r->accum, r->den_temp, (int)r->w, (int)r->h, 2);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_nd, r->den_temp, r->accum, (int)r->w, (int)r->h, 4);
+        hipLaunchKernelGGL(k_atrous, dim3(px_blocks), dim3(kBlock), 0, s, r->den_nd, r->accum, r->den_temp, (int)r->w, (int)r->h, 8);
         result = r->den_temp;
     }
     hipLaunchKernelGGL(k_composite, dim3(px_blocks), dim3(kBlock), 0, s, r->den_gbuf[cur], result, r->accum, npx);

@@ -1175,17 +1175,29 @@ __global__ __launch_bounds__(kBlock) void k_temporal(int W, int H, const float4 
     }
 }
 
+// The G-buffer's normal and depth decoded ONCE per frame for the four a-trous passes (24 taps each would decode the
+// octahedral normal again: 96 decodes per pixel): (n.x, n.y, n.z, depth), n.x = 2 marks a pixel without a primary hit.
+// The decoded values are those oct_decode returns, so the filter's result does not change by a bit.
+__global__ __launch_bounds__(kBlock) void k_decode_gbuf(const uint4 *gb, float4 *nd, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 g = gb[i];
+    if (g.x == 0xFFFFFFFFu) { nd[i] = make_float4(2.0f, 0.0f, 0.0f, __uint_as_float(g.y)); return; }
+    const f3 nn = oct_decode(g.z);
+    nd[i] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(g.y));
+}
+
 // ATrousPass (asvgf.rs:278-287): 5x5 B3-spline taps `step` pixels apart, edge-stopping on normal / depth / luminance
-__global__ __launch_bounds__(kBlock) void k_atrous(const uint4 *gb, const float4 *in, float4 *out, int W, int H, int step) {
+__global__ __launch_bounds__(kBlock) void k_atrous(const float4 *nd, const float4 *in, float4 *out, int W, int H, int step) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)(W * H)) return;
     const int y = (int)(idx / (uint32_t)W), x = (int)(idx - (uint32_t)y * (uint32_t)W);
     const float kw[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
-    const uint4 g = gb[idx];
+    const float4 g = nd[idx];
     const float4 c = in[idx];
-    if (g.x == 0xFFFFFFFFu) { out[idx] = c; return; }
-    const f3 nc = oct_decode(g.z);
-    const float zc = __uint_as_float(g.y);
+    if (g.x > 1.5f) { out[idx] = c; return; }
+    const f3 nc = mk3(g.x, g.y, g.z);
+    const float zc = g.w;
     const float lc = lum(mk3(c.x, c.y, c.z));
     const float sigma_l = 4.0f * sqrtf(max2(c.w, 0.0f)) + 1.0e-4f;
     const float sigma_z = 0.02f * zc + 1.0e-6f;
@@ -1197,11 +1209,11 @@ __global__ __launch_bounds__(kBlock) void k_atrous(const uint4 *gb, const float4
             const int qx = x + dx * step, qy = y + dy * step;
             if (qx < 0 || qy < 0 || qx >= W || qy >= H) continue;
             const size_t j = (size_t)qy * W + qx;
-            const uint4 gq = gb[j];
-            if (gq.x == 0xFFFFFFFFu) continue;
+            const float4 gq = nd[j];
+            if (gq.x > 1.5f) continue;
             const float4 q = in[j];
-            const float zq = __uint_as_float(gq.y);
-            const float wn = pow128(max2(dot(nc, oct_decode(gq.z)), 0.0f));
+            const float zq = gq.w;
+            const float wn = pow128(max2(dot(nc, mk3(gq.x, gq.y, gq.z)), 0.0f));
             const float rz = fabsf(zc - zq) / sigma_z;
             const float wz = 1.0f / (1.0f + rz * rz);
             const float rl = fabsf(lc - lum(mk3(q.x, q.y, q.z))) / sigma_l;

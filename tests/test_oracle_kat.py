@@ -165,6 +165,26 @@ def test_bvh_equals_brute_force_on_random_soup():
     assert np.array_equal(sc.trace_occluded(o, d, tmax), sc.trace_occluded(o, d, tmax, brute_force=True))
 
 
+def test_bvh_equals_brute_force_on_the_tile_that_the_64spp_4k_frame_got_wrong():
+    """Only the Woop test decides hits (SPEC §7), and its t carries the rounding of an affine map of the ray ORIGIN — at grazing
+    incidence far more than the slab arithmetic of a box test.  A tree that culls against the best hit without a margin loses a
+    triangle whose Woop t undercuts that hit by less than the difference.  Round 3's 64-spp 3840x2160 vector found such a case in
+    THIS oracle: pixel (1195, 1991), sample 52, bounce 4 — one pixel-sample in 5.3e8; the HIP path agreed with the oracle's brute
+    force over all triangles, the oracle's own tree did not (margin + per-triangle padding fixed, oracle/lpt_oracle.c box_hit /
+    tri_bounds).  The tile of that pixel, rendered alone with the seeds of that sample: tree == brute force."""
+    from loupiote_amd import scenes
+    desc = scenes.synthetic_atrium()
+    osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    W, H, PX, PY, K = 3840, 2160, 1195, 1991, 52
+    tile, world = (PY // 8) * (W // 32) + PX // 32, (W // 32) * (H // 8)       # one 32x8 tile = one "rank" of as many as there are tiles
+    a, ca = osc.render(W, H, view, T.VFOV, 8, frames=1, seed_counter=K * 8, rank=tile, world_size=world, want_counters=True)
+    b, cb = osc.render(W, H, view, T.VFOV, 8, frames=1, seed_counter=K * 8, rank=tile, world_size=world, brute_force=True, want_counters=True)
+    assert a.tobytes() == b.tobytes()
+    assert (ca.closest, ca.shadow, ca.shaded) == (cb.closest, cb.shadow, cb.shaded)
+    assert float(a[PY, PX, 0]) > 0.0
+
+
 # ---------------------------------------------------------------------------- BSDF
 def sphere_grid(n_theta=256, n_phi=512):
     ct = (np.arange(n_theta) + 0.5) / n_theta
