@@ -269,6 +269,31 @@ __global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned q
             REP16(X)
 #undef X
         }
+        else if (OP == 50) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(q));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 51) {
+#define X(i) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(u[i]) : "v"(q));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 52) {
+#define X(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(u[i]) : "v"(q), "v"(qa));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 53) {
+#define X(i) asm volatile("v_ffbh_u32_e32 %0, %1" : "=v"(u[i]) : "v"(q));
+            REP16(X)
+#undef X
+        }
+        else if (OP == 54) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(unsigned long long *)&w[i & 7]) : "v"(q), "v"(qa) : "vcc");
+            REP16(X)
+#undef X
+        }
         else if (OP == 49) {
 #define X(i) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %2, 0, %3, vcc" : : "v"(v[i]), "v"(a), "v"(u[i]), "v"(q) : "vcc");
             REP16(X)
@@ -383,6 +408,11 @@ int main() {
         run<46>("v_add_f32_e64 clamp", 16, d, w);
         run<47>("v_mul_f32_e64", 16, d, w);
         run<48>("v_fma_f32 mul:2", 16, d, w);
+        run<50>("v_mul_lo_u32", 16, d, w);
+        run<51>("v_mul_u32_u24", 16, d, w);
+        run<52>("v_bitop3_b32", 16, d, w);
+        run<53>("v_ffbh_u32", 16, d, w);
+        run<54>("v_mad_u64_u32", 16, d, w);
     }
     return 0;
 }
