@@ -77,6 +77,8 @@ def parse_args(argv=None):
     ap.add_argument("--max-fused", type=int, default=0, help="experiments: lpt_renderer_set_max_fused(n) on the timed renderer (0 = the library's default)")
     ap.add_argument("--lanes", type=int, default=0, help="experiments: wavefront lanes of the timed renderer (0 = the library's default)")
     ap.add_argument("--pageable", action="store_true", help="experiments: read_radiance() into pageable host memory")
+    ap.add_argument("--oversubscribe", action="store_true", help="tests only: ranks may share GPUs (rank -> device rank %% device count); real RCCL refuses that, "
+                    "so it needs LPT_RCCL_LIBRARY = the test stand-in (tests/tools/fake_rccl.c)")
     ap.add_argument("--spawn-dry-run", action="store_true", help="start the ranks and rendezvous over gloo only: no GPU is touched (CPU test of the launcher)")
     ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="seconds the self-started ranks may take")
     return ap.parse_args(argv)
@@ -98,7 +100,7 @@ def spawn_ranks(args):
     if not args.spawn_dry_run:
         import torch
         have = torch.cuda.device_count()
-        if have < n:
+        if have < n and not (args.oversubscribe and have >= 1):
             sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node — cannot start %d ranks (one process per GPU)\n" % (n, have, n))
             return 3
     env_base = dict(os.environ)
@@ -276,6 +278,8 @@ def run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.oversubscribe:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:

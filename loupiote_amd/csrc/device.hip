@@ -76,6 +76,9 @@ static const Rccl *rccl() {
         std::string rocm_path;
         if (const char *rp = getenv("ROCM_PATH")) rocm_path = std::string(rp) + "/lib/librccl.so";
         void *h = nullptr;
+        // LPT_RCCL_LIBRARY: another build of RCCL — or the multi-process test stand-in (tests/tools/fake_rccl.c), which lets N
+        // ranks share the one GPU of a test box; when it is set nothing else is tried
+        if (const char *lp = getenv("LPT_RCCL_LIBRARY")) { h = dlopen(lp, RTLD_NOW | RTLD_LOCAL); rocm_path.clear(); if (!h) goto rccl_done; }
         if (!rocm_path.empty()) h = dlopen(rocm_path.c_str(), RTLD_NOW | RTLD_LOCAL);
         for (size_t i = 0; !h && i < sizeof names / sizeof names[0]; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         state = -1;
@@ -90,6 +93,7 @@ static const Rccl *rccl() {
 #undef RCCL_SYM
             if (ok) state = 1;
         }
+    rccl_done:;
     }
     if (state == 1) return &table;
     fail(LPT_ERR_RCCL, "librccl could not be loaded (%s): the multi-GPU frame exchange needs RCCL", dlerror() ? dlerror() : "missing symbol");

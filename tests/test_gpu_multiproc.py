@@ -1,0 +1,71 @@
+"""-m gpu: the MULTI-PROCESS side of the tile-sharded frame on a box with one GPU.
+
+Real RCCL refuses two ranks on one device, so the N ranks of `python bench.py --gpus N --oversubscribe` (N processes that share
+GPU 0) exchange through tests/tools/fake_rccl.c — a test stand-in for the eleven librccl entry points the library resolves with
+dlsym (shared-memory mailboxes, synchronous), selected with LPT_RCCL_LIBRARY.  What this covers, for real and not by emulation:
+bench.py's launcher and its N>1 control flow (id rendezvous over gloo, one communicator per renderer, the calibrated tile
+weight, barriers, max over ranks), and the library's exchange with world > 1 in separate processes — every rank's send size
+against rank 0's receive size and staging offset (the stand-in fails on a mismatch), gather and reduce.  The exchanged frame must
+be the single-GPU frame bit for bit: the float64 checksum of the last timed frame equals the one-rank run's.  What it does not
+cover is RCCL itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "1", "--frames-per-step", "3", "--width", "480", "--height", "270", "--texture-size", "64", "--no-cpu-baseline"]
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "tools", "fake_rccl.c"),
+                           "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib"])
+    return so
+
+
+def _bench(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
+    one = _bench(["--no-extras"])
+    assert one["n_gpus"] == 1 and one["config"]["frame_complete"] is True
+    for n, mode in ((2, "gather"), (3, "reduce"), (3, "gather")):
+        j = _bench(["--gpus", str(n), "--oversubscribe", "--root-weight", "8", "--exchange", mode, "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+        assert j["n_gpus"] == n and j["rccl"]["rccl_nranks"] == n and j["rccl"]["mode"] == mode
+        assert j["rccl"]["exchange_frame_complete_on_rank0"] is True
+        assert len(j["rccl"]["per_rank_rays"]) == n and all(r > 0 for r in j["rccl"]["per_rank_rays"])
+        assert j["rccl"]["exchanges_timed"] == 3
+        # equal shares, the same number of frames before it: the last timed frame is the single-GPU frame, bit for bit
+        assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
+        assert j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+
+
+def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):
+    j = _bench(["--gpus", "2", "--oversubscribe", "--throughput", "--pipeline", "2"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    r = j["rccl"]
+    assert r["rccl_nranks"] == 2 and r["communicators_per_rank"] == 3 and r["exchange_frame_complete_on_rank0"] is True
+    assert len(r["tile_weights"]) == 2 and 1 <= r["tile_weights"][0] <= 8 and r["tile_weights"][1] in (1, 8)
+    assert r["tile_weight_calibration"]["rank0_extra_ms"] >= 0.0
+    assert j["throughput"]["communicators"] == 2 and j["throughput"]["value"] > 0 and j["latency_ms"]["median"] > 0
+    # a forced weight: rank 0 traces 3/11 of the tiles
+    k = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "3", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    assert k["rccl"]["tile_weights"] == [3, 8] and k["rccl"]["exchange_frame_complete_on_rank0"] is True
+    a, b = k["rccl"]["per_rank_rays"]
+    assert 0.2 < a / (a + b) < 0.35
+
+
+def test_a_missing_rccl_library_is_a_loud_error():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LPT_RCCL_LIBRARY"] = "/nonexistent/librccl.so"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--force-dist", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "librccl could not be loaded" in (p.stderr + p.stdout)
