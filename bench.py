@@ -399,7 +399,6 @@ def run(args):
                     span_frame()
             fence([r])
     r.reset_ray_counts()
-    r.enable_timings(True)
     fence([r])
     frame_ms = []
     t0 = time.perf_counter()
@@ -412,11 +411,19 @@ def run(args):
     elapsed = time.perf_counter() - t0
     slowest_frame = max(range(len(frame_ms)), key=lambda i: frame_ms[i]) if frame_ms else -1
     frame_ms.sort()
-    timings = r.timings()
-    r.enable_timings(False)
     c_ = r.ray_counts()
     closest_l, shadow_l, shaded_l = c_.closest, c_.shadow, c_.shaded
     n_frames = args.steps * FPS
+    # the per-stage breakdown (and the exchange time) comes from FPS more frames of the same loop with the library's event timing on:
+    # two hipEventRecord per launch delay the second wavefront's launches by ~0.1 ms per frame, so the timed region runs without them
+    r.enable_timings(True)
+    fence([r])
+    for _ in range(FPS):
+        span_frame()
+    fence([r])
+    timings = r.timings()
+    r.enable_timings(False)
+    r.reset_ray_counts()
 
     tl = torch.tensor([elapsed], dtype=torch.float64)
     rays = torch.tensor([closest_l, shadow_l, shaded_l], dtype=torch.float64)
@@ -469,7 +476,7 @@ def run(args):
     # shares the chip.  The kernel figure (roofline.frac) is taken from SOLO_FRAMES frames issued as ONE wavefront each
     # (lpt_renderer_set_max_fused(spp)), one frame at a time: un-overlapped launches, HIP events on the stream they run on.
     SOLO_FRAMES = 3
-    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l, shadow_l)
+    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l / n_frames * FPS, shadow_l / n_frames * FPS)
     r.set_max_fused(max(SPP, 1))
     span_frame()                       # the lanes' ray buffers grow to the batch size on first use
     fence([r])
@@ -640,7 +647,7 @@ def run(args):
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
-            "stage_ms_per_frame": {k: v[0] / n_frames for k, v in timings.items()},
+            "stage_ms_per_frame": {k: v[0] / FPS for k, v in timings.items()},
             "stage_ms_per_frame_solo": {k: v[0] / SOLO_FRAMES for k, v in solo_t.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,
                       "tri_bytes": accel.tri_bytes, "depth": accel.max_depth, "build_ms": accel.build_ms},
