@@ -134,6 +134,18 @@ def main(tag, out):
     wv, wc, bc = per_launch(k, "SQ_WAVES"), per_launch(k, "SQ_WAVE_CYCLES"), per_launch(k, "SQ_BUSY_CYCLES")
     if wv:
         lim["waves_per_launch"] = wv
+    # wave occupancy (north star: "wave occupancy counters"): SQ_WAVE_CYCLES counts quad-cycles of resident waves; against the launch's busy cycles
+    # (GRBM_GUI_ACTIVE / 8 XCDs) on 1024 SIMDs that is the average number of waves resident per SIMD (8 = full for k_trace, 4 for k_shade)
+    occ = {}
+    for kk, cap in ((k, 8), (k2, 4)):
+        wcy, gg = per_launch(kk, "SQ_WAVE_CYCLES"), per_launch(kk, "GRBM_GUI_ACTIVE")
+        if wcy and gg:
+            occ[kk] = {"waves_per_simd": 4.0 * wcy / ((gg / 8.0) * SIMDS), "max_waves_per_simd": cap,
+                       "wait_any_share": (per_launch(kk, "SQ_WAIT_ANY") or 0.0) / wcy, "issue_stall_share": (per_launch(kk, "SQ_WAIT_INST_ANY") or 0.0) / wcy,
+                       "valu_active_share": (per_launch(kk, "SQ_ACTIVE_INST_VALU") or 0.0) / wcy}
+    if occ:
+        occ["what"] = "waves_per_simd = 4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); shares = of a resident wave's cycles: parked on s_waitcnt (memory), issue-stalled, issuing VALU"
+        lim["occupancy"] = occ
     json.dump(lim, open(os.path.join(out, "limits.json"), "w"), indent=1)
     print(json.dumps(lim, indent=1))
     print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1))
