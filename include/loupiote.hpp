@@ -167,8 +167,9 @@ class Renderer {  // renderer.rs:169-811
     void set_max_bounces(uint32_t n) { check(lpt_renderer_set_max_bounces(h_, n)); }
     void set_seed(uint32_t s) { check(lpt_renderer_set_seed(h_, s)); }
     void set_vfov(float radians) { check(lpt_renderer_set_vfov(h_, radians)); }
-    void set_shard(uint32_t rank, uint32_t world, uint32_t tile_w = 32, uint32_t tile_h = 8) { check(lpt_renderer_set_shard(h_, rank, world, tile_w, tile_h)); }
-    void set_comm(const Comm *comm) { check(lpt_renderer_set_comm(h_, comm ? comm->handle() : nullptr)); }     // = set_shard(rank, world, 32, 8) + the binding
+    /// `weights` (one small integer per rank, the same on every rank; nullptr = equal shares): unequal tile shares, e.g. fewer tiles for the rank that also assembles the frame
+    void set_shard(uint32_t rank, uint32_t world, uint32_t tile_w = 32, uint32_t tile_h = 8, const uint32_t *weights = nullptr) { check(lpt_renderer_set_shard_weighted(h_, rank, world, tile_w, tile_h, weights)); }
+    void set_comm(const Comm *comm, const uint32_t *weights = nullptr) { check(lpt_renderer_set_comm_weighted(h_, comm ? comm->handle() : nullptr, weights)); }     // = set_shard(rank, world, 32, 8, weights) + the binding
     void exchange(int mode = LPT_EXCHANGE_GATHER_TILES) { check(lpt_renderer_exchange(h_, mode)); }             // rank 0 presents the whole frame
     void set_sort_queues(int flag) { check(lpt_renderer_set_sort_queues(h_, flag)); }
     lpt_ray_counts ray_counts() { lpt_ray_counts c; check(lpt_renderer_get_ray_counts(h_, &c)); return c; }
