@@ -468,12 +468,10 @@ int lpt_renderer_exchange(lpt_renderer *r, int mode);
  * Used by single-process hosts and by the tests that emulate N ranks on one GPU. */
 int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, int n_peers);
 
-/* new (no reference knob): the number of wavefront lanes of a renderer (1..4, default 2).  Consecutive raytrace() calls take
- * the lanes in turn, each on its own HIP stream with its own ray queues, so the traversal of call k+1 overlaps the drain
- * tails of call k; accumulation stays in call order on the renderer's stream, so results do not change by a bit.  It is
- * what lets a caller that issues its samples one raytrace() at a time (the reference's protocol) keep the GPU busy; a
- * renderer whose frames are already overlapped with other renderers' gains nothing from it.  Costs one set of ray
- * buffers per lane in use. */
+/* new (no reference knob): the number of wavefront lanes of a renderer (1..4, default 2).  Consecutive SUBMISSIONS (the fused
+ * batches of recorded raytrace() calls, or lpt_renderer_raytrace_n calls) take the lanes in turn, each on its own HIP stream
+ * with its own ray queues, so the shading of one wavefront overlaps the traversal of the next; accumulation stays in call
+ * order on the renderer's stream, so results do not change by a bit.  Costs one set of ray buffers per lane in use. */
 int lpt_renderer_set_lanes(lpt_renderer *r, int lanes);
 /* new (north star: "a sorted shade / next-event stage using wavefront ballot / prefix-sum"; the reference dispatches the
  * full pixel grid unsorted, renderer.rs:484-509).  flag != 0: the shading pass writes the next-bounce and the shadow-ray

@@ -2,11 +2,14 @@
 //
 // Host orchestration of one frame follows Renderer::raytrace
 // (reference crates/lib/src/renderer.rs:392-549): pass order, the seed / bounces /
-// frame_count protocol and the accumulate flag.  A renderer enqueues on its own HIP stream (accumulation,
+// frame_count protocol and the accumulate flag.  raytrace() RECORDS (the reference records into an encoder the app submits
+// once, app.rs:335-337); a submission point launches the recorded calls as wavefronts of several samples per pixel
+// (record_call / flush_pending / submit_wavefront).  A renderer enqueues on its own HIP stream (accumulation,
 // filter passes, reads, the frame exchange: in call order) and on the streams of its wavefront lanes (the
-// traversal / shading of consecutive raytrace() calls, overlapped); nothing here waits for the GPU except the
+// traversal / shading of consecutive wavefronts, overlapped); nothing here waits for the GPU except the
 // read-back calls (the reference's only blocking point is read_pixels, :791) and scene edits.
-// Also here: the multi-GPU frame exchange (plain RCCL: lpt_comm_*, lpt_renderer_exchange).
+// Also here: the multi-GPU frame exchange (plain RCCL, opened with dlopen: lpt_comm_*, lpt_renderer_exchange) and the
+// tile-ownership rule (weighted shards).
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
