@@ -1449,10 +1449,10 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
-        // persistent waves: about 4 primary rays per lane, between 8 and 32 waves per CU.  A small frame (a tile shard
-        // of a multi-GPU frame) runs faster on fewer, longer-lived waves — measured on a 1/8 shard: 16 waves/CU 2.11 ms,
-        // 32 waves/CU 2.32 ms — while the full frame wants all 32 (12.04 vs 12.54 ms at 16).
-        uint32_t waves = r->trace_waves_per_cu ? cus * r->trace_waves_per_cu : std::min(std::max(n_rays / 256u, cus * 8u), cus * 32u);
+        // persistent waves: about 2.5 primary rays per lane, between 8 and 32 waves per CU.  The full frame wants all 32; a 1/8
+        // tile shard (1 M rays per launch) is best at 24 (round 3, span form: 8 / 12 / 16 / 24 / 32 waves per CU -> 4.41 / 3.89 /
+        // 3.62 / 3.51 / 3.54 ms per frame)
+        uint32_t waves = r->trace_waves_per_cu ? cus * r->trace_waves_per_cu : std::min(std::max(n_rays / 160u, cus * 8u), cus * 32u);
         waves = std::max(8u, waves & ~7u);  // whole groups of 8: one chunk head per XCD
         const uint32_t trace_blocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), waves);
         const size_t lds = stack_bytes(sc);
