@@ -336,6 +336,9 @@ int lpt_renderer_submit(lpt_renderer *r);
  * take the renderer's wavefront lanes in turn and overlap), 1 = every raytrace() launches immediately (the round-2
  * behaviour), up to 64.  Costs ray-queue memory: 176 B per ray in flight and wavefront lane. */
 int lpt_renderer_set_max_fused(lpt_renderer *r, uint32_t n);
+/* new: what record-then-submit has done so far — raytrace() calls recorded (with resources set), wavefronts launched for them,
+ * and calls recorded but not yet submitted.  Pure host state: does not submit, does not wait. */
+int lpt_renderer_get_submission_stats(const lpt_renderer *r, uint64_t *recorded_calls, uint64_t *wavefronts, uint32_t *pending_calls);
 /* Build-only batching of the call above: exactly equivalent (bit for bit) to
  * n x { lpt_renderer_raytrace(r, view); accumulate = true (app.rs:318); } but traced as ONE wavefront
  * of n samples per pixel (sample-major queues), which keeps the persistent traversal waves fed.

@@ -113,6 +113,7 @@ SIGNATURES = {
     "lpt_renderer_raytrace_n": (_i, [_vp, _vp, _u32]),
     "lpt_renderer_submit": (_i, [_vp]),
     "lpt_renderer_set_max_fused": (_i, [_vp, _u32]),
+    "lpt_renderer_get_submission_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _pu32]),
     "lpt_host_alloc": (_i, [_sz, _pvp]),
     "lpt_host_free": (_i, [_vp]),
     "lpt_renderer_reset_accumulation": (_i, [_vp]),

@@ -349,6 +349,12 @@ class Renderer:
         """recorded raytrace() calls one submission may fuse into a wavefront: 0 = automatic, 1 = every call launches at once"""
         _check(A.lib().lpt_renderer_set_max_fused(self._h, int(n)))
 
+    def submission_stats(self):
+        """(raytrace() calls recorded, wavefronts launched for them, calls recorded but not yet submitted) — host state only"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(A.lib().lpt_renderer_get_submission_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def reset_accumulation(self):
         _check(A.lib().lpt_renderer_reset_accumulation(self._h))
 

@@ -178,6 +178,7 @@ struct lpt_renderer {
     // (frame_count, seed, frame_back) moves at record time, the snapshot below is what the launches use.
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
     uint32_t max_fused = 0;    // samples one submission may fuse; 0 = auto (about 4 M rays per wavefront), 1 = every call launches at once
+    uint64_t n_recorded = 0, n_wavefronts = 0;   // raytrace() calls recorded / wavefronts submitted so far (lpt_renderer_get_submission_stats)
     int mode = LPT_BLIT_PATHTRACE;
     // build-only knobs
     uint32_t max_bounces = 3, user_seed = 0;
@@ -1538,6 +1539,7 @@ static int flush_pending(lpt_renderer *r) {
     if (!r->pend.n) return LPT_OK;
     const lpt_renderer::Pending b = r->pend;
     r->pend.n = 0;
+    r->n_wavefronts++;
     return submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0);
 }
 
@@ -1572,6 +1574,7 @@ static int record_call(lpt_renderer *r, const float view[16]) {
         b.frame_count0 = r->frame_count; b.seed0 = r->seed; b.acc0 = r->accumulate;
     }
     b.n++;
+    r->n_recorded++;
     r->seed += r->max_bounces;                   // seed += 1 per intersect stage, never reset
     if (pathtrace && r->accumulate) r->frame_count += 1u;   // frame_count only moves in the Pathtrace arm (:523-538)
     // the denoising modes carry frame-to-frame state (one temporal pass per call): they launch at once; so does a full batch
@@ -1587,6 +1590,14 @@ int lpt_renderer_raytrace(lpt_renderer *r, const float view[16]) {
 int lpt_renderer_submit(lpt_renderer *r) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_submit: null");
     return flush_pending(r);
+}
+
+int lpt_renderer_get_submission_stats(const lpt_renderer *r, uint64_t *recorded_calls, uint64_t *wavefronts, uint32_t *pending_calls) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_submission_stats: null");
+    if (recorded_calls) *recorded_calls = r->n_recorded;
+    if (wavefronts) *wavefronts = r->n_wavefronts;
+    if (pending_calls) *pending_calls = r->pend.n;
+    return LPT_OK;
 }
 
 int lpt_renderer_set_max_fused(lpt_renderer *r, uint32_t n) {

@@ -128,7 +128,9 @@ def test_batches_are_cut_at_the_cap_and_nothing_is_lost_on_destroy(device, corne
     for _ in range(7):                           # 3 + 3 launch when full, 1 stays recorded
         r.raytrace(view)
     assert r.frame_state() == (8, 7 * DEPTH)     # the protocol state moves at record time
+    assert r.submission_stats() == (7, 2, 1)     # seven calls recorded, two full batches launched, one call still recorded
     img = r.read_radiance()
+    assert r.submission_stats() == (7, 3, 0)     # the read submitted it
     r.raytrace(view)                             # recorded, never submitted
     r.close()
     e = _renderer(device, sg, pr, 1)
@@ -150,7 +152,9 @@ def test_atrium_frame_of_the_unchanged_caller_equals_the_batched_frame(device):
         for _ in range(4):
             a.raytrace(view)
         dst = lp.pinned_array((270, 480, 4))     # page-locked read-back destination (lpt_host_alloc)
+        assert a.submission_stats() == (4, 0, 4)         # 480x270: the four calls of the frame wait for the read as ONE wavefront
         ia = a.read_radiance(out=dst).copy()
+        assert a.submission_stats() == (4, 1, 0)
         b = _renderer(device, sg, pr, 0, size=(480, 270))
         b.raytrace_n(view, 4)
         assert ia.tobytes() == b.read_radiance().tobytes()
