@@ -401,6 +401,7 @@ def run(args):
     r.reset_ray_counts()
     fence([r])
     frame_ms = []
+    sub0 = r.submission_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for _ in range(FPS):
@@ -409,6 +410,7 @@ def run(args):
             frame_ms.append((time.perf_counter() - tf) * 1e3)
     fence([r])
     elapsed = time.perf_counter() - t0
+    sub1 = r.submission_stats()
     slowest_frame = max(range(len(frame_ms)), key=lambda i: frame_ms[i]) if frame_ms else -1
     frame_ms.sort()
     c_ = r.ray_counts()
@@ -615,6 +617,7 @@ def run(args):
                                       "; lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", "pageable" if args.pageable else "page-locked", FPS),
                        "texture_bytes": tex_bytes, "textures": len(desc["images"]), "materials": len(desc["materials"]),
                        "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed, "submission": "eager" if args.eager else "record-then-submit",
+                       "raytrace_calls_per_frame": (sub1[0] - sub0[0]) / max(args.steps * FPS, 1), "wavefronts_per_frame": (sub1[1] - sub0[1]) / max(args.steps * FPS, 1),
                        "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum},
