@@ -35,6 +35,7 @@ Besides `value` the line carries
 import argparse
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -161,12 +162,17 @@ def spawn_ranks(args):
         return procs[failed].returncode or 1
     reader.join(timeout=10)
     lines = [l for l in (box.get("out") or "").splitlines() if l.startswith("{")]
+    rc = 0
     if not lines:
         sys.stderr.write("bench.py --gpus %d: rank 0 printed no JSON line\n---- rank 0 stderr (tail) ----\n%s\n" % (n, tail(0)))
-        return 5
-    sys.stdout.write(lines[-1] + "\n")
-    sys.stdout.flush()
-    return 0
+        rc = 5
+    else:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    for f in logs:
+        f.close()
+    shutil.rmtree(tmp, ignore_errors=True)   # the ranks' logs: only of interest when something failed (reported above)
+    return rc
 
 
 def dry_run(args):

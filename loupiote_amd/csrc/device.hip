@@ -239,11 +239,17 @@ struct lpt_renderer {
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 // submits the recorded raytrace() calls; every synchronisation point, and every setter whose value the launches read, runs it first
 static int flush_pending(lpt_renderer *r);
+static void forget_deferred_exchange(lpt_renderer *r);
 #define FLUSH_OR_RETURN(r) do { int fst__ = flush_pending(r); if (fst__ != LPT_OK) return fst__; } while (0)
 // Recorded raytrace() calls saw the scene / probe as it was when they were issued: an edit (or a destroy) submits them first.
-static void flush_device(lpt_device *dev) {
-    if (!dev) return;
-    for (lpt_renderer *r : dev->renderers) flush_pending(r);
+static int flush_device(lpt_device *dev) {
+    int st = LPT_OK;
+    if (!dev) return st;
+    for (lpt_renderer *r : dev->renderers) {
+        const int f = flush_pending(r);
+        if (st == LPT_OK) st = f;   // the first failure is what the caller reports (lpt_last_error holds its text)
+    }
+    return st;
 }
 // what read_radiance / read_pixels / blit show: the exchanged whole frame after lpt_renderer_exchange, else the local target
 static inline const float4 *presented_target(const lpt_renderer *r) { return (r->presented && r->frame) ? r->frame : r->accum; }
@@ -699,7 +705,7 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
     hipStream_t s = sg->dev->stream;
     // renderers trace on their own streams and raytrace() is asynchronous: frames still in flight read the triangles and
     // nodes this call rewrites in place, so wait for every stream of the device first
-    flush_device(sg->dev);
+    { const int fst = flush_device(sg->dev); if (fst != LPT_OK) return fst; }
     HIP_TRY(hipDeviceSynchronize());
     uint32_t changed = 0;
     for (size_t i = 0; i < scene->instances.size(); ++i) {
@@ -753,7 +759,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
     if (n < 16u) return lpt_scene_gpu_update_instances(sg, scene, nullptr);
     HIP_TRY(hipSetDevice(sg->dev->ordinal));
     hipStream_t s = sg->dev->stream;
-    flush_device(sg->dev);
+    { const int fst = flush_device(sg->dev); if (fst != LPT_OK) return fst; }
     HIP_TRY(hipDeviceSynchronize());  // frames in flight on the renderers' streams still read what is rebuilt here
     void *woop_prim = nullptr;
     HIP_TRY(hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)n));
@@ -1109,6 +1115,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     if (!r) return LPT_OK;
     hipSetDevice(r->dev->ordinal);
     r->pend.n = 0;   // recorded but never submitted: nobody can read the result any more
+    forget_deferred_exchange(r);   // an exchange enqueued inside a still open lpt_comm_group bracket must not outlive the renderer
     {
         auto &v = r->dev->renderers;
         v.erase(std::remove(v.begin(), v.end(), r), v.end());
@@ -2024,6 +2031,9 @@ static int exchange_finish(lpt_renderer *r, int mode) {
 struct DeferredFinish { lpt_renderer *r; int mode; };
 static thread_local int t_group_depth = 0;
 static thread_local std::vector<DeferredFinish> t_deferred;
+static void forget_deferred_exchange(lpt_renderer *r) {
+    t_deferred.erase(std::remove_if(t_deferred.begin(), t_deferred.end(), [r](const DeferredFinish &d) { return d.r == r; }), t_deferred.end());
+}
 
 extern "C" {
 
