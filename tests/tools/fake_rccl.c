@@ -5,7 +5,7 @@
  * sizes and staging offsets of every rank — can run on a box with ONE GPU, where real RCCL refuses two ranks on one device.
  * Selected with LPT_RCCL_LIBRARY=<this .so> (tests/test_gpu_multiproc.py); never loaded otherwise.
  *
- * Transport: a POSIX shared-memory segment named after the unique id, one mailbox per ordered (src, dst) pair, 4 MiB chunks,
+ * Transport: a POSIX shared-memory segment named after the unique id, one mailbox per ordered (src, dst) pair, 1 MiB chunks,
  * everything synchronous: an operation first waits for the stream it was enqueued on, then moves the bytes with hipMemcpy
  * from the calling thread.  Group brackets are no-ops.  Sum reductions (float32 / int32) are done on the host by the root.
  * It says nothing about RCCL itself — that is what the 8-GPU run is for.
@@ -29,7 +29,7 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclI
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 
-#define CHUNK (4u << 20)
+#define CHUNK (1u << 20)
 #define MAX_RANKS 8
 typedef struct {
     _Atomic uint64_t sent, taken;   /* chunks published / consumed */
