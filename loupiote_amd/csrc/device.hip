@@ -71,6 +71,7 @@ struct Rccl {
 static const Rccl *rccl() {
     static Rccl table;
     static int state = 0;   // 0 = not tried, 1 = loaded, -1 = failed
+    static std::string why = "missing symbol";   // dlerror() of the failed attempt (it reads once: a second call returns NULL)
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (state == 1) return &table;
@@ -81,10 +82,11 @@ static const Rccl *rccl() {
         void *h = nullptr;
         // LPT_RCCL_LIBRARY: another build of RCCL — or the multi-process test stand-in (tests/tools/fake_rccl.c), which lets N
         // ranks share the one GPU of a test box; when it is set nothing else is tried
-        if (const char *lp = getenv("LPT_RCCL_LIBRARY")) { h = dlopen(lp, RTLD_NOW | RTLD_LOCAL); rocm_path.clear(); if (!h) goto rccl_done; }
+        state = -1;
+        if (const char *lp = getenv("LPT_RCCL_LIBRARY")) { h = dlopen(lp, RTLD_NOW | RTLD_LOCAL); rocm_path.clear(); if (!h) { if (const char *e = dlerror()) why = e; goto rccl_done; } }
         if (!rocm_path.empty()) h = dlopen(rocm_path.c_str(), RTLD_NOW | RTLD_LOCAL);
         for (size_t i = 0; !h && i < sizeof names / sizeof names[0]; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-        state = -1;
+        if (!h) { if (const char *e = dlerror()) why = e; }
         if (h) {
             table.handle = h;
             bool ok = true;
@@ -99,7 +101,7 @@ static const Rccl *rccl() {
     rccl_done:;
     }
     if (state == 1) return &table;
-    fail(LPT_ERR_RCCL, "librccl could not be loaded (%s): the multi-GPU frame exchange needs RCCL", dlerror() ? dlerror() : "missing symbol");
+    fail(LPT_ERR_RCCL, "librccl could not be loaded (%s): the multi-GPU frame exchange needs RCCL", why.c_str());
     return nullptr;
 }
 
@@ -912,8 +914,14 @@ static void free_denoiser(lpt_renderer *r) {
     r->den_cur = 1;
 }
 
+static int alloc_denoiser(lpt_renderer *r);
 static int ensure_denoiser(lpt_renderer *r) {
     if (r->den_temp) return LPT_OK;
+    const int st = alloc_denoiser(r);
+    if (st != LPT_OK) free_denoiser(r);   // all or nothing: a later call starts over instead of leaking the part that was allocated
+    return st;
+}
+static int alloc_denoiser(lpt_renderer *r) {
     const size_t n = (size_t)r->w * r->h;
     hipStream_t s = r->stream;
     for (int k = 0; k < 2; ++k) {
@@ -927,9 +935,9 @@ static int ensure_denoiser(lpt_renderer *r) {
         HIP_TRY(hipMemsetAsync(r->den_hist[k], 0, sizeof(uint32_t) * n, s));  // history 0 = nothing to reproject
     }
     HIP_TRY(hipMalloc(&r->den_motion, sizeof(float2) * n));
-    HIP_TRY(hipMalloc(&r->den_temp, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&r->den_noisy, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&r->den_nd, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&r->den_temp, sizeof(float4) * n));   // the "allocated" marker (ensure_denoiser)
     HIP_TRY(hipMemsetAsync(r->den_noisy, 0, sizeof(float4) * n, s));
     HIP_TRY(hipMemsetAsync(r->den_motion, 0, sizeof(float2) * n, s));
     HIP_TRY(hipStreamSynchronize(s));   // the primary pass of the first frame may run on a lane's stream
@@ -1137,7 +1145,10 @@ int lpt_renderer_destroy(lpt_renderer *r) {
     if (r->stream) hipStreamDestroy(r->stream);
     if (r->noise) hipFree(r->noise);
     if (r->ev_start) {
-        for (int i = 0; i < lpt_renderer::kRing * lpt_renderer::kMaxEvents; ++i) { hipEventDestroy(r->ev_start[i]); hipEventDestroy(r->ev_stop[i]); }
+        for (int i = 0; i < lpt_renderer::kRing * lpt_renderer::kMaxEvents; ++i) {
+            if (r->ev_start[i]) hipEventDestroy(r->ev_start[i]);
+            if (r->ev_stop[i]) hipEventDestroy(r->ev_stop[i]);
+        }
         delete[] r->ev_start;
         delete[] r->ev_stop;
     }
@@ -1307,9 +1318,14 @@ int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     const int total = lpt_renderer::kRing * lpt_renderer::kMaxEvents;
     if (flag && !r->ev_start) {
-        r->ev_start = new hipEvent_t[total];
-        r->ev_stop = new hipEvent_t[total];
-        for (int i = 0; i < total; ++i) { HIP_TRY(hipEventCreate(&r->ev_start[i])); HIP_TRY(hipEventCreate(&r->ev_stop[i])); }
+        r->ev_start = new hipEvent_t[total]();   // null until created: a failure half way leaves nothing undefined for destroy
+        r->ev_stop = new hipEvent_t[total]();
+    }
+    if (flag) {
+        for (int i = 0; i < total; ++i) {
+            if (!r->ev_start[i]) HIP_TRY(hipEventCreate(&r->ev_start[i]));
+            if (!r->ev_stop[i]) HIP_TRY(hipEventCreate(&r->ev_stop[i]));
+        }
     }
     if (flag) {  // (re)start accumulating
         HIP_TRY(hipStreamSynchronize(r->stream));

@@ -22,7 +22,7 @@ def bvh_check(tmp_path_factory):
     return exe
 
 
-def run(exe, tmp_path, tris, rays, mode=None, eye=None):
+def run(exe, tmp_path, tris, rays, mode=None, eye=None, reinsert=None):
     path = str(tmp_path / "soup.bin")
     tris = np.ascontiguousarray(tris, "<f4").reshape(-1, 9)
     with open(path, "wb") as f:
@@ -31,6 +31,8 @@ def run(exe, tmp_path, tris, rays, mode=None, eye=None):
     env = dict(os.environ)
     if mode:
         env["LPT_BVH_COLLAPSE"] = mode
+    if reinsert is not None:
+        env["LPT_BVH_REINSERT"] = reinsert
     cmd = [exe, path, str(rays), "1"] + ([str(v) for v in eye] if eye else [])
     p = subprocess.run(cmd, env=env, capture_output=True, text=True)
     out = json.loads(p.stdout.strip().splitlines()[-1])
@@ -82,3 +84,24 @@ def test_grid_mesh_quality(bvh_check, tmp_path):
     gr = run(bvh_check, tmp_path, tris, 20000, "greedy", eye=(0, 0, 8))
     assert dp["mismatches"] == gr["mismatches"] == 0 and dp["hits"] == gr["hits"]
     assert dp["nodes"] < 0.8 * gr["nodes"] and dp["nodes_per_ray"] <= 1.02 * gr["nodes_per_ray"]
+
+
+@pytest.mark.parametrize("reinsert", ["0", "1,0.05", "12,1.0"])
+def test_reinsertion_optimiser_keeps_every_hit(bvh_check, tmp_path, reinsert):
+    """the insertion-based optimisation of the binary tree (bvh.cpp Reinserter) only moves subtrees: whatever its settings
+    (off, light, every node twelve times), random rays find exactly the brute-force hits and every triangle sits in one leaf"""
+    rng = np.random.default_rng(11)
+    soup = np.concatenate([random_soup(rng, 2500), random_soup(rng, 1500, extent=2.0, size=0.05), random_soup(rng, 40, extent=8.0, size=6.0)])
+    out = run(bvh_check, tmp_path, soup, 6000, reinsert=reinsert)
+    assert out["triangles"] == len(soup) and out["mismatches"] == 0 and out["bad_refs"] == 0 and out["hits"] > 0
+    assert out["depth"] <= 30
+
+
+def test_reinsertion_optimiser_does_not_cost_visits(bvh_check, tmp_path):
+    """clustered geometry of mixed scale (long triangles across clusters of small ones): the optimised tree is not worse"""
+    rng = np.random.default_rng(5)
+    soup = np.concatenate([random_soup(rng, 6000, extent=10.0, size=0.15), random_soup(rng, 200, extent=6.0, size=5.0)])
+    off = run(bvh_check, tmp_path, soup, 20000, reinsert="0")
+    on = run(bvh_check, tmp_path, soup, 20000)
+    assert off["mismatches"] == on["mismatches"] == 0 and off["hits"] == on["hits"]
+    assert on["nodes_per_ray"] <= 1.01 * off["nodes_per_ray"]
