@@ -10,7 +10,8 @@ Workload (BASELINE.json metric: "Mrays/s (+ ms/frame) at 1920x1080, 4 spp, Sponz
     per FRAME:  reset_accumulation(); accumulate = true; 4 x Renderer::raytrace(view); [N>1: lpt_renderer_exchange];
                 read_radiance()  (rank 0; blocking, into page-locked host memory; the other ranks synchronise)
   raytrace() RECORDS (record-then-submit, include/lpt.h): the four calls of a frame are launched by the next submission
-  point as one wavefront of 4 samples per pixel, bit-identical to four separate launches.
+  point — read_radiance — as wavefronts of 4 samples per pixel (at 1920x1080: two, the upper and the lower half of the image,
+  each read back as soon as it is complete), bit-identical to four separate launches.
   A STEP = FRAMES_PER_STEP (10) such frames, so that the driver's `--steps 20` times about 2.5 s instead of 0.25 s.
   value = (closest-hit + shadow rays traced by all ranks in the K timed steps) / wall time, in Mrays/s, with barrier +
   torch.cuda.synchronize() on both sides and the MAX over ranks.
@@ -354,7 +355,7 @@ def run(args):
         r.reset_accumulation()
         r.accumulate = True                      # app.rs:318
         for _ in range(SPP):
-            r.raytrace(view)                     # records; the four calls leave as one wavefront
+            r.raytrace(view)                     # records; the four calls leave together at the next submission point
         if comms:
             r.exchange(xmode)                    # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
         if rank == 0:
@@ -480,7 +481,7 @@ def run(args):
         byts = (cl * b_ray + sh * b_sh) / max(launches, 1)
         return avg, launches, byts, (byts / (avg * 1e-3) / 1e9 if avg > 0 else 0.0)
 
-    # In the timed region the 4 samples of a frame leave as two wavefronts on the renderer's two lanes and overlap: a launch there
+    # In the timed region the 4 samples of a frame leave as two wavefronts (half the tile rows each) on the renderer's two lanes and overlap: a launch there
     # shares the chip.  The kernel figure (roofline.frac) is taken from SOLO_FRAMES frames issued as ONE wavefront each
     # (lpt_renderer_set_max_fused(spp)), one frame at a time: un-overlapped launches, HIP events on the stream they run on.
     SOLO_FRAMES = 3
@@ -618,7 +619,7 @@ def run(args):
             "data": "synthetic",
             "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in: %d triangles, %d textures = %.1f MB of texels, %d materials], %dx%d, %d spp, depth %d, "
                                    "camera (-10,1,0)->(1,0.35,0); frame = the SURVEY 8d span on one renderer per GPU: reset_accumulation; %d x raytrace(view) "
-                                   "(recorded, submitted as one wavefront)%s; read_radiance() into %s host memory on rank 0; step = %d frames"
+                                   "(recorded; submitted by the read as 4-sample wavefronts over runs of tile rows)%s; read_radiance() into %s host memory on rank 0; step = %d frames"
                                    % (accel.triangles, len(desc["images"]), tex_bytes / 1e6, len(desc["materials"]), WIDTH, HEIGHT, SPP, DEPTH, SPP,
                                       "; lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", "pageable" if args.pageable else "page-locked", FPS),
                        "texture_bytes": tex_bytes, "textures": len(desc["images"]), "materials": len(desc["materials"]),
@@ -643,7 +644,7 @@ def run(args):
                                   "stream the kernel runs on around every k_trace launch — the duration rocprofv3's kernel trace reports for `bench.py --max-fused 4 --lanes 1` "
                                   "(profiles/*_solo_kernel_stats.csv)" % SOLO_FRAMES,
                          "timed_region": {"achieved": o_achieved, "frac": o_achieved / HBM_PEAK_GBS, "avg_launch_ms": o_avg, "launches": o_launches, "bytes_per_launch": o_bytes,
-                                          "note": "the same over the timed region, where the two 2-sample wavefronts of a frame overlap on the renderer's lanes: a launch shares "
+                                          "note": "the same over the timed region, where the two 4-sample half-frame wavefronts of a frame overlap on the renderer's lanes: a launch shares "
                                                   "the chip with the other wavefront's kernels — a scheduling figure, not a kernel figure"},
                          "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
                                     "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation, the read-back): a lower bound"},

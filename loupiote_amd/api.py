@@ -346,7 +346,8 @@ class Renderer:
         _check(A.lib().lpt_renderer_submit(self._h))
 
     def set_max_fused(self, n):
-        """recorded raytrace() calls one submission may fuse into a wavefront: 0 = automatic, 1 = every call launches at once"""
+        """0 = automatic (recorded calls wait for the next submission point and leave as wavefronts of about 4 M rays: runs of tile
+        rows with all the samples); n >= 1: n calls are one whole-frame wavefront, launched when the n-th is recorded (1 = at once)"""
         _check(A.lib().lpt_renderer_set_max_fused(self._h, int(n)))
 
     def submission_stats(self):

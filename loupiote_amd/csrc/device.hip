@@ -151,12 +151,13 @@ struct Wavefront {
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr;
     FrameCounters *ctr = nullptr;
-    uint32_t batch_cap = 0;         // samples per pixel the per-ray buffers can hold (raytrace_n); 0 = not allocated yet
+    size_t ray_cap = 0;             // rays (pixel slots x samples) the per-ray buffers can hold; 0 = not allocated yet
     hipEvent_t done = nullptr;      // recorded on `stream` behind the lane's last traversal / shading launch
     hipEvent_t consumed = nullptr;  // recorded on the renderer's stream behind the accumulation that read this lane's Lsum
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
+constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
 struct lpt_renderer {
     lpt_device *dev = nullptr;
@@ -179,7 +180,9 @@ struct lpt_renderer {
     // view that continue one accumulation fuse into ONE wavefront of `n` samples per pixel; the host-side protocol state
     // (frame_count, seed, frame_back) moves at record time, the snapshot below is what the launches use.
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
-    uint32_t max_fused = 0;    // samples one submission may fuse; 0 = auto (about 4 M rays per wavefront), 1 = every call launches at once
+    uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
+                               // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
+    uint64_t wavefront_rays = kWavefrontRays;   // LPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
     uint64_t n_recorded = 0, n_wavefronts = 0;   // raytrace() calls recorded / wavefronts submitted so far (lpt_renderer_get_submission_stats)
     int mode = LPT_BLIT_PATHTRACE;
     // build-only knobs
@@ -240,7 +243,7 @@ struct lpt_renderer {
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 // submits the recorded raytrace() calls; every synchronisation point, and every setter whose value the launches read, runs it first
-static int flush_pending(lpt_renderer *r);
+static int flush_pending(lpt_renderer *r, float *read_dst = nullptr);
 static void forget_deferred_exchange(lpt_renderer *r);
 #define FLUSH_OR_RETURN(r) do { int fst__ = flush_pending(r); if (fst__ != LPT_OK) return fst__; } while (0)
 // Recorded raytrace() calls saw the scene / probe as it was when they were issued: an edit (or a destroy) submits them first.
@@ -949,7 +952,7 @@ static void free_ray_buffers(Wavefront &wf) {
     for (void *p : ptrs) if (p) hipFree(p);
     wf.q[0] = Queue{}; wf.q[1] = Queue{}; wf.sq = ShadowQueue{};
     wf.hits = wf.Lsum = nullptr;
-    wf.batch_cap = 0;
+    wf.ray_cap = 0;
 }
 
 static void free_frame_buffers(lpt_renderer *r) {
@@ -1023,11 +1026,11 @@ static void shard_geometry(const lpt_renderer *r, uint32_t &tiles_x, uint32_t &n
     n_slots = owned_tiles(r->map, n_tiles) * r->tile_w * r->tile_h;
 }
 
-// per-ray buffers of one lane (queues, hits, shadow queue, per-sample radiance): n_slots * samples elements
-static int alloc_ray_buffers(lpt_renderer *r, Wavefront &wf, uint32_t samples) {
+// per-ray buffers of one lane (queues, hits, shadow queue, per-sample radiance): one element per ray of a wavefront
+static int alloc_ray_buffers(Wavefront &wf, size_t rays) {
     free_ray_buffers(wf);
-    const size_t n = std::max<size_t>((size_t)r->n_slots * samples, 64);
-    if (n > 0x7FFFFFFFull) return fail(LPT_ERR_INVALID_ARG, "batch of %u samples x %u pixel slots exceeds 2^31 rays", samples, r->n_slots);
+    const size_t n = std::max<size_t>(rays, 64);
+    if (n > 0x7FFFFFFFull) return fail(LPT_ERR_INVALID_ARG, "a wavefront of %zu rays exceeds 2^31", n);
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipMalloc(&wf.q[k].o, sizeof(float4) * n));
         HIP_TRY(hipMalloc(&wf.q[k].d, sizeof(float4) * n));
@@ -1038,7 +1041,7 @@ static int alloc_ray_buffers(lpt_renderer *r, Wavefront &wf, uint32_t samples) {
     HIP_TRY(hipMalloc(&wf.sq.c, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&wf.hits, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&wf.Lsum, sizeof(float4) * n));
-    wf.batch_cap = samples;
+    wf.ray_cap = n;
     return LPT_OK;
 }
 
@@ -1086,6 +1089,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     if (const char *ev = getenv("LPT_SORT")) r->sort_queues = atoi(ev) & 3;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
+    if (const char *ev = getenv("LPT_WAVEFRONT_RAYS")) r->wavefront_rays = (uint64_t)std::max(64ll, atoll(ev));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
     r->prev_cam.fwd = mk3(0.f, 0.f, 1.f); r->prev_cam.ax = r->prev_cam.ay = 1.0f;   // Mat4::IDENTITY (renderer.rs:319)
     r->req_w = width; r->req_h = height;
@@ -1394,9 +1398,12 @@ static void launch_filter(lpt_renderer *r, hipStream_t s) {
 
 extern "C" {
 
-// The launches of `n_samples` recorded raytrace() calls as ONE wavefront, from the protocol state the first of them saw
-// (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with accumulate == true by construction).
-static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0) {
+// The launches of `n_samples` recorded raytrace() calls as ONE wavefront over the rank's pixel slots [slot0, slot0 + piece_slots),
+// from the protocol state the first of them saw (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with
+// accumulate == true by construction).  `read_dst` (world == 1, Pathtrace): the mean radiance of the pixel rows
+// [row0, row1) this wavefront completes is resolved and copied to the host right behind its accumulation (flush_pending).
+static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0,
+                            uint32_t slot0, uint32_t piece_slots, float *read_dst = nullptr, uint32_t row0 = 0, uint32_t row1 = 0) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     hipStream_t sm = r->stream;                  // accumulation, filter passes, bookkeeping, reads, the exchange: in call order
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
@@ -1415,6 +1422,8 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
     p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
     p.map = r->map;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
+    p.slot0 = slot0;
+    p.n_slots = piece_slots;                     // the slots of THIS wavefront
     p.frame_count = frame_count0;
     p.max_bounces = nb;
     p.n_samples = n_samples;
@@ -1432,10 +1441,10 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
     Wavefront &wf = r->wf[lane];
     hipStream_t s = split ? wf.stream : sm;
     r->last_lane = lane;
-    if (n_samples > wf.batch_cap && p.n_slots) {
+    if ((size_t)n_rays > wf.ray_cap && p.n_slots) {
         HIP_TRY(hipStreamSynchronize(sm));       // everything that read this lane's buffers has been enqueued behind `sm`'s waits
         HIP_TRY(hipStreamSynchronize(s));
-        int st = alloc_ray_buffers(r, wf, n_samples);
+        int st = alloc_ray_buffers(wf, n_rays);
         if (st != LPT_OK) return st;
     }
     GBufArgs gb{};
@@ -1537,6 +1546,12 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
             stage_begin(r, ST_ACCUM, sm);
             hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, sm, p, wf.Lsum, r->accum);
             stage_end(r, sm);
+            if (read_dst && row1 > row0) {
+                // these pixel rows are final: their read-back overlaps the wavefronts that are still tracing the other rows
+                const size_t off = (size_t)row0 * r->w, cnt = (size_t)(row1 - row0) * r->w;
+                hipLaunchKernelGGL(k_resolve, dim3(div_up((uint32_t)cnt, kBlock)), dim3(kBlock), 0, sm, r->accum + off, r->scratch + off, (uint32_t)cnt);
+                HIP_TRY(hipMemcpyAsync(read_dst + 4u * off, r->scratch + off, sizeof(float4) * cnt, hipMemcpyDeviceToHost, sm));
+            }
         } else {
             // per-pixel filter inputs; on a sharded frame (world > 1) the caller now exchanges noisy / gbuffer / motion
             // (lpt_renderer_denoiser_inputs) and rank 0 calls lpt_renderer_denoise_filter
@@ -1557,24 +1572,47 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
     return LPT_OK;
 }
 
-// submit what has been recorded (every synchronisation point and every setter that the launches read calls this first)
-static int flush_pending(lpt_renderer *r) {
+// Submit what has been recorded (every synchronisation point and every setter that the launches read calls this first).
+// With an explicit batch size (lpt_renderer_set_max_fused(n >= 1), lpt_renderer_raytrace_n) the recorded calls are ONE wavefront.
+// Otherwise a batch of more than about 4 M rays is cut SPATIALLY — runs of whole tile rows (of whole tiles on a sharded frame),
+// every run with all the recorded samples — and the pieces take the renderer's lanes in turn: at 1920x1080 the 4 samples of a
+// frame leave as two wavefronts of 4.1 M rays (the upper and the lower half of the image), the shading of one overlaps the
+// traversal of the other (measured for two 4 M-ray wavefronts: 13.30 ms per frame against 13.68 for one 8 M-ray wavefront and
+// 14.1 for four 2 M-ray ones), and the piece that was launched first is complete about one stage before the last:
+// `read_dst` (lpt_renderer_read_radiance) has every piece's rows copied to the host as soon as they are final.
+static int flush_pending(lpt_renderer *r, float *read_dst) {
     if (!r->pend.n) return LPT_OK;
     const lpt_renderer::Pending b = r->pend;
     r->pend.n = 0;
-    r->n_wavefronts++;
-    return submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0);
-}
-
-static uint32_t fuse_cap(const lpt_renderer *r) {
-    if (r->max_fused) return r->max_fused;
     uint32_t tiles_x, n_tiles, n_slots;
     shard_geometry(r, tiles_x, n_tiles, n_slots);
-    // about 4 M rays per wavefront: 2 samples at 1920x1080, so that the 4 samples of a frame leave as two wavefronts on the
-    // renderer's two lanes and the shading of one overlaps the traversal of the other (measured: 13.30 ms per frame against
-    // 13.68 for one 8 M-ray wavefront and 14.1 for four 2 M-ray ones)
-    return std::max(1u, std::min(64u, (1u << 22) / std::max(n_slots, 1u)));
+    const uint32_t area = r->tile_w * r->tile_h;
+    const bool whole_rows = r->world == 1u;                       // the rank's slots are the tiles in row-major order
+    const uint32_t granule = whole_rows ? tiles_x * area : area;  // slots per tile row / per tile
+    const uint32_t granules = granule ? n_slots / granule : 0u;
+    uint32_t per_piece = granules;
+    if (!r->max_fused && r->mode == LPT_BLIT_PATHTRACE && granules > 1u && (uint64_t)n_slots * b.n > r->wavefront_rays) {
+        const uint64_t fit = r->wavefront_rays / ((uint64_t)granule * b.n);           // granules of b.n samples in about 4 M rays
+        const uint32_t pieces = div_up(granules, (uint32_t)std::max<uint64_t>(fit, 1u));
+        per_piece = div_up(granules, pieces);                     // the same number of pieces, evened out
+    }
+    if (!granules) {   // nothing owned (a compositor rank): one empty wavefront keeps the bookkeeping of the call
+        r->n_wavefronts++;
+        return submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, 0u, 0u);
+    }
+    const bool early = read_dst && whole_rows && r->mode == LPT_BLIT_PATHTRACE;
+    for (uint32_t g0 = 0; g0 < granules; g0 += per_piece) {
+        const uint32_t g1 = std::min(granules, g0 + per_piece);
+        r->n_wavefronts++;
+        const int st = submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule,
+                                        early ? read_dst : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
+        if (st != LPT_OK) return st;
+    }
+    return LPT_OK;
 }
+
+// recorded calls that may wait for one submission
+static uint32_t fuse_cap(const lpt_renderer *r) { return r->max_fused ? r->max_fused : 64u; }
 
 // Records ONE raytrace() call: the host-side protocol of Renderer::raytrace moves now (frame_back :401, seed :453/:487,
 // frame_count :535-537), the launches wait for the next submission point.  A call fuses with the recorded ones when it
@@ -1641,8 +1679,8 @@ int lpt_renderer_raytrace_n(lpt_renderer *r, const float view[16], uint32_t n_sa
         st = record_call(r, view);
         if (n_samples > 1u) r->accumulate = true;
     }
+    if (st == LPT_OK) st = flush_pending(r);   // still with the explicit batch size: one wavefront, not the automatic spatial cut
     r->max_fused = keep;
-    if (st == LPT_OK) st = flush_pending(r);
     return st;
 }
 
@@ -1671,6 +1709,16 @@ int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes)
 
 int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (!r || !dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance: null");
+    if (r->pend.n && r->accum && r->world == 1u && r->mode == LPT_BLIT_PATHTRACE) {
+        // the frame is still recorded: submit it with its own read-back — every wavefront's pixel rows travel to the host as
+        // soon as they are final, under the wavefronts that are still tracing (the recorded calls clear `presented`, so the
+        // local target is what is shown)
+        const int st = flush_pending(r, dst);
+        if (st != LPT_OK) return st;
+        const hipError_t se = hipStreamSynchronize(r->stream);
+        if (se != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(se));
+        return LPT_OK;
+    }
     FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);

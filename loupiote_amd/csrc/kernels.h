@@ -101,6 +101,10 @@ struct FrameParams {
     uint32_t user_seed, seed_counter;
     ShardMap map;
     uint32_t rank, world, tile_w, tile_h, tiles_x, n_tiles, n_slots;
+    // a wavefront may cover only a run of the rank's slots (device.hip flush_pending: a batch too large for one wavefront is cut
+    // spatially): n_slots = the slots of this wavefront, slot0 = the first of them among the rank's slots.  Everything inside a
+    // wavefront (queues, Lsum) is indexed by the local slot; only the slot -> pixel map needs slot0
+    uint32_t slot0;
     uint32_t frame_count, max_bounces;
     // batched samples (lpt_renderer_raytrace_n): sample k of the batch behaves like the k-th of n
     // consecutive raytrace() calls: seeds advance by max_bounces per sample, frame_count by fc_inc0
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
         const uint32_t sample = vslot / p.n_slots, slot = vslot - sample * p.n_slots;
         const uint32_t seed_counter = p.seed_counter + sample * p.max_bounces;
         uint32_t x = 0, y = 0;
-        const bool valid = vslot < total && slot_to_pixel(p, slot, x, y);
+        const bool valid = vslot < total && slot_to_pixel(p, p.slot0 + slot, x, y);
         if (vslot < total) Lsum[vslot] = make_float4(0.f, 0.f, 0.f, 0.f);
         f3 d = mk3(0.f, 0.f, 0.f);
         if (valid) {
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
         uint32_t x, y;
-        if (!slot_to_pixel(p, slot, x, y)) continue;
+        if (!slot_to_pixel(p, p.slot0 + slot, x, y)) continue;
         const size_t px = (size_t)y * p.width + x;
         uint32_t fc = p.frame_count;
         float4 a = fc == 1u ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[px];
@@ -1128,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_den_scatter(FrameParams p, const flo
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
         uint32_t x, y;
-        if (!slot_to_pixel(p, slot, x, y)) continue;
+        if (!slot_to_pixel(p, p.slot0 + slot, x, y)) continue;
         noisy[(size_t)y * p.width + x] = Lsum[slot];
     }
 }

@@ -164,3 +164,62 @@ def test_atrium_frame_of_the_unchanged_caller_equals_the_batched_frame(device):
         DEPTH = keep
     pr.close()
     sg.close()
+
+
+def _cut_renderer(device, sg, pr, monkeypatch, rays, size, lanes):
+    """an automatic renderer whose submissions are cut into wavefronts of about `rays` rays (LPT_WAVEFRONT_RAYS is read at creation)"""
+    monkeypatch.setenv("LPT_WAVEFRONT_RAYS", str(rays))
+    r = _renderer(device, sg, pr, 0, lanes, size=size)
+    monkeypatch.delenv("LPT_WAVEFRONT_RAYS")
+    return r
+
+
+@pytest.mark.parametrize("size,lanes", [((203, 117), 2), ((203, 117), 1), ((256, 128), 2), ((97, 301), 3)])
+def test_a_large_batch_is_cut_into_runs_of_tile_rows_and_read_back_piece_by_piece(device, cornell, monkeypatch, size, lanes):
+    """a recorded batch of more than ~4 M rays (here: of more than LPT_WAVEFRONT_RAYS) leaves as several wavefronts, each a run of tile
+    rows with ALL the samples; read_radiance has each run copied to the host behind its own accumulation.  Bit for bit the
+    frame of one wavefront, of eager launches, and of the ordinary read path; frames that continue an accumulation too."""
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    w, h = size
+    tile_rows = -(-h // 8)
+    ref = _renderer(device, sg, pr, 1, size=size)            # eager: one launch per call
+    cut = _cut_renderer(device, sg, pr, monkeypatch, 3 * 256 * -(-w // 32) * 4, size, lanes)   # about three tile rows of 4 samples
+    for _ in range(4):
+        ref.raytrace(view); cut.raytrace(view)
+    assert cut.submission_stats() == (4, 0, 4)
+    dst = lp.pinned_array((h, w, 4))
+    a = cut.read_radiance(out=dst).copy()                    # submits: the pieces carry their own read-back
+    rec, wavefronts, pending = cut.submission_stats()
+    assert (rec, pending) == (4, 0) and wavefronts == -(-tile_rows // 3)
+    assert a.tobytes() == ref.read_radiance().tobytes()
+    assert a.tobytes() == cut.read_radiance().tobytes()      # nothing recorded: the ordinary path, same frame
+    # three more calls continue the accumulation (another cut: 3 samples per piece), then a view change resets nothing by itself
+    for _ in range(3):
+        ref.raytrace(view); cut.raytrace(view)
+    v2 = T.look((0.5, 0.4, 12.0), (-0.05, 0.02, -1.0))
+    ref.raytrace(v2); cut.raytrace(v2)                       # another view: a new batch (the first is submitted, cut, without a read)
+    b = cut.read_radiance()
+    assert b.tobytes() == ref.read_radiance().tobytes()
+    assert _state(cut) == _state(ref)
+    ref.close(); cut.close()
+
+
+def test_the_cut_frame_equals_the_oracle_and_explicit_batches_stay_whole(device, cornell, cornell_glb, monkeypatch):
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    cut = _cut_renderer(device, sg, pr, monkeypatch, 20000, (W, H), 2)
+    for _ in range(4):
+        cut.raytrace(view)
+    img = cut.read_radiance()
+    ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
+    assert img.tobytes() == ref.tobytes()
+    c = cut.ray_counts()
+    assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+    assert cut.submission_stats()[1] > 4
+    cut.close()
+    whole = _cut_renderer(device, sg, pr, monkeypatch, 20000, (W, H), 2)
+    whole.raytrace_n(view, 4)                                 # the explicit batch: ONE wavefront whatever its size
+    assert whole.submission_stats() == (4, 1, 0)
+    assert whole.read_radiance().tobytes() == ref.tobytes()
+    whole.close()
