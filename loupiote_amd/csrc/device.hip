@@ -1398,12 +1398,19 @@ static void launch_filter(lpt_renderer *r, hipStream_t s) {
 
 extern "C" {
 
-// The launches of `n_samples` recorded raytrace() calls as ONE wavefront over the rank's pixel slots [slot0, slot0 + piece_slots),
-// from the protocol state the first of them saw (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with
-// accumulate == true by construction).  `read_dst` (world == 1, Pathtrace): the mean radiance of the pixel rows
-// [row0, row1) this wavefront completes is resolved and copied to the host right behind its accumulation (flush_pending).
-static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0,
-                            uint32_t slot0, uint32_t piece_slots, float *read_dst = nullptr, uint32_t row0 = 0, uint32_t row1 = 0) {
+// A wavefront between its two halves (flush_pending): what the second half needs to know about the first
+struct Ticket {
+    FrameParams p;
+    int lane = 0;
+    bool split = false, denoise = false;
+    CamBasis cur{};
+};
+
+// First half of a wavefront: the launches of `n_samples` recorded raytrace() calls over the rank's pixel slots
+// [slot0, slot0 + piece_slots) — ray generation, traversal, shading — on the wavefront's lane, from the protocol state the first
+// of the calls saw (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with accumulate == true by construction).
+static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0,
+                           uint32_t slot0, uint32_t piece_slots, Ticket &tk) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     hipStream_t sm = r->stream;                  // accumulation, filter passes, bookkeeping, reads, the exchange: in call order
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
@@ -1536,11 +1543,25 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
                 stage_end(r, s);
             }
         }
-        // the wavefront is done; what follows reads its radiance on the renderer's stream, behind every earlier call's
-        if (split) {
-            HIP_TRY(hipEventRecord(wf.done, s));
-            HIP_TRY(hipStreamWaitEvent(sm, wf.done, 0));
-        }
+        if (split) HIP_TRY(hipEventRecord(wf.done, s));
+        HIP_TRY(hipGetLastError());
+    }
+    tk.p = p; tk.lane = lane; tk.split = split; tk.denoise = denoise; tk.cur = gb.cur;
+    return LPT_OK;
+}
+
+// Second half, on the renderer's stream behind every earlier call's: what reads the wavefront's radiance — accumulation (or the
+// denoiser's inputs and filter) and the bookkeeping.  `read_dst` (world == 1, Pathtrace): the mean radiance of the pixel rows
+// [row0, row1) this wavefront completes is resolved and copied to the host right behind its accumulation.
+static int wavefront_finish(lpt_renderer *r, const Ticket &tk, float *read_dst, uint32_t row0, uint32_t row1) {
+    hipStream_t sm = r->stream;
+    const FrameParams &p = tk.p;
+    Wavefront &wf = r->wf[tk.lane];
+    const bool split = tk.split;
+    const uint32_t nb = p.max_bounces;
+    if (p.n_slots) {
+        const uint32_t stream_blocks = std::min<uint32_t>(div_up(p.n_slots * p.n_samples, kBlock), (uint32_t)r->dev->compute_units * 8u);
+        if (split) HIP_TRY(hipStreamWaitEvent(sm, wf.done, 0));
         if (r->mode == LPT_BLIT_PATHTRACE) {
             // AccumulationPass (:523-538)
             stage_begin(r, ST_ACCUM, sm);
@@ -1568,7 +1589,7 @@ static int submit_wavefront(lpt_renderer *r, const float view[16], uint32_t n_sa
         }
         HIP_TRY(hipGetLastError());
     }
-    if (denoise) r->prev_cam = gb.cur;           // prev_model_to_screen = P * V^-1 (:542-546)
+    if (tk.denoise) r->prev_cam = tk.cur;        // prev_model_to_screen = P * V^-1 (:542-546)
     return LPT_OK;
 }
 
@@ -1596,18 +1617,30 @@ static int flush_pending(lpt_renderer *r, float *read_dst) {
         const uint32_t pieces = div_up(granules, (uint32_t)std::max<uint64_t>(fit, 1u));
         per_piece = div_up(granules, pieces);                     // the same number of pieces, evened out
     }
+    Ticket tk[kMaxLanes];
     if (!granules) {   // nothing owned (a compositor rank): one empty wavefront keeps the bookkeeping of the call
         r->n_wavefronts++;
-        return submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, 0u, 0u);
+        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, 0u, 0u, tk[0]);
+        return st != LPT_OK ? st : wavefront_finish(r, tk[0], nullptr, 0u, 0u);
     }
+    // The first halves run ahead of the second halves by the number of lanes: wavefront k's launches are enqueued before the
+    // renderer's stream is given the accumulation (and the read-back copy, which blocks the host when `read_dst` is pageable
+    // memory) of wavefront k - lanes — the wavefront that used the same lane, whose buffers k overwrites.
     const bool early = read_dst && whole_rows && r->mode == LPT_BLIT_PATHTRACE;
-    for (uint32_t g0 = 0; g0 < granules; g0 += per_piece) {
-        const uint32_t g1 = std::min(granules, g0 + per_piece);
+    const uint32_t ahead = (r->mode != LPT_BLIT_PATHTRACE || r->n_lanes < 2) ? 1u : (uint32_t)r->n_lanes;
+    const uint32_t pieces = div_up(granules, per_piece);
+    auto finish = [&](uint32_t k) {
+        const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
+        return wavefront_finish(r, tk[k % ahead], early ? read_dst : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
+    };
+    for (uint32_t k = 0; k < pieces; ++k) {
+        if (k >= ahead) { const int st = finish(k - ahead); if (st != LPT_OK) return st; }
+        const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
         r->n_wavefronts++;
-        const int st = submit_wavefront(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule,
-                                        early ? read_dst : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
+        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule, tk[k % ahead]);
         if (st != LPT_OK) return st;
     }
+    for (uint32_t k = pieces > ahead ? pieces - ahead : 0u; k < pieces; ++k) { const int st = finish(k); if (st != LPT_OK) return st; }
     return LPT_OK;
 }
 
