@@ -116,19 +116,23 @@ def main(tag, out):
     vt, vs = per_launch(k, "SQ_INSTS_VALU"), per_launch(k2, "SQ_INSTS_VALU")
     gt = per_launch(k, "GRBM_GUI_ACTIVE")
     b2 = {}
-    p2 = os.path.join(out, tag + "_bench.json")
-    if os.path.exists(p2):
-        try:
-            b2 = json.loads(open(p2).read().strip())
-        except Exception:
-            b2 = {}
+    # the frame time of an UN-profiled run when there is one (rocprofv3's kernel trace slows the frame by ~15 %): <tag>_bench_full.json
+    # beside the pass directories or under profiles/; else the bench line of the trace pass
+    for p2 in (os.path.join(os.path.dirname(out.rstrip("/")), tag + "_bench_full.json"), os.path.join("profiles", tag + "_bench_full.json"), os.path.join(out, tag + "_bench.json")):
+        if os.path.exists(p2):
+            try:
+                b2 = json.loads([l for l in open(p2) if l.startswith("{")][-1])
+                b2["_source"] = p2
+                break
+            except Exception:
+                b2 = {}
     if vt and vs and gt and avg_ns and b2.get("ms_per_frame"):
         clock = (gt / 8.0) / (avg_ns * 1e-9)                      # Hz the PMC pass actually ran at
         ceiling = 1.0 / (FAST_SHARE / FAST_RATE + (1 - FAST_SHARE) / SLOW_RATE)
         insts = 9.0 * vt + 8.0 * vs
         bound_ms = insts / SIMDS / ceiling / clock * 1e3
         lim["frame_valu"] = {"valu_wave_insts_per_frame": insts, "k_trace_share": 9.0 * vt / insts, "bound_ms_per_frame": bound_ms,
-                             "measured_ms_per_frame": b2["ms_per_frame"], "frac": bound_ms / b2["ms_per_frame"], "clock_hz": clock,
+                             "measured_ms_per_frame": b2["ms_per_frame"], "measured_from": b2.get("_source"), "frac": bound_ms / b2["ms_per_frame"], "clock_hz": clock,
                              "note": "all VALU wave-instructions of a frame (9 k_trace + 8 k_shade launches) at the issue ceiling of k_trace's mix vs the "
                                      "measured frame (the SURVEY 8d span: one renderer, read-back included)"}
     wv, wc, bc = per_launch(k, "SQ_WAVES"), per_launch(k, "SQ_WAVE_CYCLES"), per_launch(k, "SQ_BUSY_CYCLES")
