@@ -188,3 +188,30 @@ def test_rccl_one_rank_communicator_without_torch():
     print(p.stdout[-3000:], p.stderr[-3000:])
     assert p.returncode == 0
     assert "COMM_ONE_RANK_OK" in p.stdout
+
+
+@pytest.mark.parametrize("world,weights", [(2, None), (3, (1, 3, 2))])
+def test_sharded_frames_cut_into_runs_of_tiles_equal_one_gpu(device, cornell_glb, monkeypatch, world, weights):
+    """a recorded batch too large for one wavefront on a SHARDED frame is cut into runs of the rank's tiles (not tile rows; no
+    piecewise read-back): four recorded calls per frame on every emulated rank, cut small, exchanged — the single-GPU frame"""
+    sg, pr = _setup(device, cornell_glb)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    w, h = 203, 117
+    one = _renderer(device, sg, pr, w, h, 4)
+    monkeypatch.setenv("LPT_WAVEFRONT_RAYS", "6000")          # about five 32x8 tiles of 4 samples per wavefront
+    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, (32, 8), weights) for q in range(world)]
+    monkeypatch.delenv("LPT_WAVEFRONT_RAYS")
+    for frame in range(2):
+        for _ in range(4):
+            one.raytrace(view)
+            for r in ranks:
+                r.raytrace(view)
+        assert all(r.submission_stats()[2] == 4 for r in ranks)   # still recorded
+        ranks[0].exchange_local(ranks[1:])
+        assert ranks[0].read_radiance().tobytes() == one.read_radiance().tobytes(), "frame %d" % frame
+    assert ranks[1].submission_stats()[1] > 2 * 3                 # several wavefronts per frame
+    assert sum(r.ray_counts().closest for r in ranks) == one.ray_counts().closest
+    for r in ranks + [one]:
+        r.close()
+    pr.close()
+    sg.close()
