@@ -533,6 +533,10 @@ def run(args):
         lat.sort()
         latency = {"min": lat[0], "median": lat[len(lat) // 2], "frames": len(lat),
                    "what": "one frame alone: reset_accumulation + 4 x raytrace(view)%s + stream synchronize (no read-back)" % (" + exchange" if comms else "")}
+        if readback is not None:
+            # what the span pays for its read-back: the read that ends a frame submits it and copies every wavefront's rows as soon as they are
+            # final (include/lpt.h lpt_renderer_read_radiance), so part of `median_ms` hides under the wavefronts that are still tracing
+            readback["exposed_in_span_ms"] = elapsed / n_frames * 1e3 - latency["median"]
     r.close()
 
     # ================================================================== throughput: P renderers in flight, batched samples, no read-back
