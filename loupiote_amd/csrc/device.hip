@@ -182,6 +182,7 @@ struct lpt_renderer {
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
     uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
                                // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
+    uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_PIPE_RAYS=0: none
     uint64_t wavefront_rays = kWavefrontRays;   // LPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
     uint64_t n_recorded = 0, n_wavefronts = 0;   // raytrace() calls recorded / wavefronts submitted so far (lpt_renderer_get_submission_stats)
     int mode = LPT_BLIT_PATHTRACE;
@@ -1089,6 +1090,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     if (const char *ev = getenv("LPT_SORT")) r->sort_queues = atoi(ev) & 3;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
+    if (const char *ev = getenv("LPT_PIPE_RAYS")) r->pipe_rays = (uint32_t)std::max(0ll, std::min(0x7FFFFFFFll, atoll(ev)));
     if (const char *ev = getenv("LPT_WAVEFRONT_RAYS")) r->wavefront_rays = (uint64_t)std::max(64ll, atoll(ev));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
     r->prev_cam.fwd = mk3(0.f, 0.f, 1.f); r->prev_cam.ax = r->prev_cam.ay = 1.0f;   // Mat4::IDENTITY (renderer.rs:319)
@@ -1489,10 +1491,14 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
-        // persistent waves: about 2.5 primary rays per lane, between 8 and 32 waves per CU.  The full frame wants all 32; a 1/8
-        // tile shard (1 M rays per launch) is best at 24 (round 3, span form: 8 / 12 / 16 / 24 / 32 waves per CU -> 4.41 / 3.89 /
-        // 3.62 / 3.51 / 3.54 ms per frame)
-        uint32_t waves = r->trace_waves_per_cu ? cus * r->trace_waves_per_cu : std::min(std::max(n_rays / 160u, cus * 8u), cus * 32u);
+        // the one-round-trip step (kernels.h ray_step_pipe): 78 VGPRs, so 6 waves per SIMD instead of 8, ~3 % more nodes and ~12 % more
+        // triangles fetched per ray — and still 1 % less time per frame at 8 M rays, 2 % for a 1 M-ray tile shard
+        // (profiles/r03c_experiments_ab.txt); LPT_PIPE_RAYS=0 selects the two-round-trip step
+        const bool pipe = n_rays <= r->pipe_rays;
+        // persistent waves: about 2.5 primary rays per lane, between 8 waves per CU and all that fit (24 at 78 VGPRs, 32 at 59).  A 1/8
+        // tile shard (1 M rays per launch) is best at 24 either way (round 3, span form, two-round-trip step: 8 / 12 / 16 / 24 / 32
+        // waves per CU -> 4.41 / 3.89 / 3.62 / 3.51 / 3.54 ms per frame)
+        uint32_t waves = r->trace_waves_per_cu ? cus * r->trace_waves_per_cu : std::min(std::max(n_rays / 160u, cus * 8u), cus * (pipe ? 24u : 32u));
         waves = std::max(8u, waves & ~7u);  // whole groups of 8: one chunk head per XCD
         const uint32_t trace_blocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), waves);
         const size_t lds = stack_bytes(sc);
@@ -1514,8 +1520,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
-            if (r->stats) hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
-            else hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+            if (pipe) {
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
             stage_end(r, s);
         };
         if (r->merge_trace) trace(0, -1);
