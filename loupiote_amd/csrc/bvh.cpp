@@ -442,7 +442,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     if (use_dp && n >= 64u) {
         // LPT_BVH_REINSERT="passes,fraction" (experiments); "0" keeps the tree as the top-down build left it
         // defaults: 4 passes over the 30 % largest boxes — on the 262 k-triangle atrium 2.6 % fewer nodes per ray and 1.7 % less
-        // traversal time for 3x the (host) build time; more passes add little (profiles/r03c_experiments_ab.txt)
+        // traversal time for 3x the (host) build time; more passes add little (profiles/r03_experiments_ab.txt)
         int passes = 4;
         float fraction = 0.3f;
         if (const char *ev = getenv("LPT_BVH_REINSERT")) { float f = fraction; const int got = sscanf(ev, "%d,%f", &passes, &f); if (got == 2 && f > 0.f && f <= 1.f) fraction = f; }

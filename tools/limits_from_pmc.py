@@ -28,8 +28,9 @@ GATHER_TBS = (9.7, 13.5)
 
 
 def short(name):
-    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+    # k_trace<STATS, PIPE>: the first template argument (the STATS variant is a different kernel for the averages), not the second
+    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))?>)?", name)
+    return (m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")) if m else name[:40]
 
 
 def main(tag, out):
@@ -139,9 +140,9 @@ def main(tag, out):
     if wv:
         lim["waves_per_launch"] = wv
     # wave occupancy (north star: "wave occupancy counters"): SQ_WAVE_CYCLES counts quad-cycles of resident waves; against the launch's busy cycles
-    # (GRBM_GUI_ACTIVE / 8 XCDs) on 1024 SIMDs that is the average number of waves resident per SIMD (8 = full for k_trace, 4 for k_shade)
+    # (GRBM_GUI_ACTIVE / 8 XCDs) on 1024 SIMDs that is the average number of waves resident per SIMD (6 = full for k_trace, 4 for k_shade)
     occ = {}
-    for kk, cap in ((k, 8), (k2, 4)):
+    for kk, cap in ((k, 6), (k2, 4)):   # resident waves per SIMD the kernels' VGPR counts allow: k_trace<., PIPE> 78 -> 6, k_shade 127 -> 4
         wcy, gg = per_launch(kk, "SQ_WAVE_CYCLES"), per_launch(kk, "GRBM_GUI_ACTIVE")
         if wcy and gg:
             occ[kk] = {"waves_per_simd": 4.0 * wcy / ((gg / 8.0) * SIMDS), "max_waves_per_simd": cap,

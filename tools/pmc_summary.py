@@ -7,9 +7,10 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)>)?", name)
+    # k_trace<STATS, PIPE>: keyed by the first template argument (the STATS variant is a different kernel for the averages)
+    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))?>)?", name)
     if m:
-        return m.group(1) + (m.group(2) or "")
+        return m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")
     return name[:40]
 
 
