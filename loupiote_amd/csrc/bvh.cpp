@@ -154,6 +154,7 @@ struct Builder {
 // triangle stays in exactly one leaf, so the traversal results cannot change.
 struct Reinserter {
     struct Item { float induced; int32_t id; };
+    static constexpr int kMaxPops = 512;
     static bool later(const Item &a, const Item &b) { return a.induced > b.induced; }   // min-heap on the induced cost
     std::vector<BuildNode> &n;
     std::vector<int32_t> parent;
@@ -181,9 +182,12 @@ struct Reinserter {
         heap.push_back({root_growth, n[0].left});
         heap.push_back({root_growth, n[0].right});
         std::make_heap(heap.begin(), heap.end(), later);
-        float best_cost = 1e30f;
+        // the place it came from is the first candidate, so the search — capped at kMaxPops nodes: coincident or heavily overlapping
+        // boxes (hostile input) give the bound nothing to prune with — can only improve on it
+        float best_cost = join(n[S].box, nb).half_area();
+        for (int32_t a = G; a >= 0; a = parent[a]) best_cost += join(n[a].box, nb).half_area() - n[a].box.half_area();
         int32_t X = S;
-        while (!heap.empty()) {
+        for (int pops = 0; !heap.empty() && pops < kMaxPops; ++pops) {
             std::pop_heap(heap.begin(), heap.end(), later);
             const Item it = heap.back();
             heap.pop_back();
