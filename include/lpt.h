@@ -367,7 +367,9 @@ int lpt_renderer_set_blit_mode(lpt_renderer *r, int mode);
  * Any pointer may be NULL.  Blocking.  Parity surface for the denoiser path. */
 int lpt_renderer_read_denoiser(lpt_renderer *r, uint32_t *gbuffer, float *motion, float *radiance, uint32_t *history);
 /* replaces: Renderer::blit(&Device,&mut encoder,&TextureView) (renderer.rs:551-607):
- * tonemapped sRGB RGBA8 of the current target into caller memory. */
+ * tonemapped sRGB RGBA8 of the current target into caller memory.  Like lpt_renderer_read_radiance, a frame that is still
+ * recorded is submitted together with its read-back: every wavefront's pixel rows are tonemapped and copied as soon as
+ * that wavefront has been accumulated (single-GPU Pathtrace frames; also lpt_renderer_read_pixels). */
 int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes);
 /* replaces: async Renderer::read_pixels -> Result<Vec<u8>,Error> (renderer.rs:727-811).
  * Blocking (the reference's device.poll(Wait), :791); w*h*4 bytes, tight rows. */

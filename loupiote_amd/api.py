@@ -369,11 +369,13 @@ class Renderer:
     def set_blit_mode(self, mode):
         _check(A.lib().lpt_renderer_set_blit_mode(self._h, int(mode)))
 
-    def blit(self):
+    def blit(self, row_bytes=None):
+        """tonemapped sRGB RGBA8 of the current target; `row_bytes` >= w * 4: a destination with padded rows (the padding stays zero)"""
         w, h = self.get_size()
-        out = np.zeros((h, w, 4), np.uint8)
-        _check(A.lib().lpt_renderer_blit_rgba8(self._h, A.ptr(out), w * 4))
-        return out
+        pitch = w * 4 if row_bytes is None else int(row_bytes)
+        buf = np.zeros((h, pitch), np.uint8)
+        _check(A.lib().lpt_renderer_blit_rgba8(self._h, A.ptr(buf), pitch))
+        return buf[:, :w * 4].reshape(h, w, 4) if row_bytes is None else buf
 
     def read_pixels(self):
         w, h = self.get_size()

@@ -244,7 +244,13 @@ struct lpt_renderer {
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 // submits the recorded raytrace() calls; every synchronisation point, and every setter whose value the launches read, runs it first
-static int flush_pending(lpt_renderer *r, float *read_dst = nullptr);
+// what a submission copies to the host as its wavefronts complete (lpt_renderer_read_radiance / lpt_renderer_blit_rgba8)
+struct ReadPlan {
+    float *radiance = nullptr;      // mean radiance, w*h*4 floats, tight rows
+    uint8_t *rgba8 = nullptr;       // or: tonemapped sRGB RGBA8 ...
+    size_t row_bytes = 0;           // ... with this row pitch
+};
+static int flush_pending(lpt_renderer *r, const ReadPlan *read = nullptr);
 static void forget_deferred_exchange(lpt_renderer *r);
 #define FLUSH_OR_RETURN(r) do { int fst__ = flush_pending(r); if (fst__ != LPT_OK) return fst__; } while (0)
 // Recorded raytrace() calls saw the scene / probe as it was when they were issued: an edit (or a destroy) submits them first.
@@ -1560,9 +1566,9 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
 }
 
 // Second half, on the renderer's stream behind every earlier call's: what reads the wavefront's radiance — accumulation (or the
-// denoiser's inputs and filter) and the bookkeeping.  `read_dst` (world == 1, Pathtrace): the mean radiance of the pixel rows
-// [row0, row1) this wavefront completes is resolved and copied to the host right behind its accumulation.
-static int wavefront_finish(lpt_renderer *r, const Ticket &tk, float *read_dst, uint32_t row0, uint32_t row1) {
+// denoiser's inputs and filter) and the bookkeeping.  `read` (world == 1, Pathtrace): the pixel rows [row0, row1) this wavefront
+// completes are resolved (or tonemapped) and copied to the host right behind its accumulation.
+static int wavefront_finish(lpt_renderer *r, const Ticket &tk, const ReadPlan *read, uint32_t row0, uint32_t row1) {
     hipStream_t sm = r->stream;
     const FrameParams &p = tk.p;
     Wavefront &wf = r->wf[tk.lane];
@@ -1576,11 +1582,17 @@ static int wavefront_finish(lpt_renderer *r, const Ticket &tk, float *read_dst, 
             stage_begin(r, ST_ACCUM, sm);
             hipLaunchKernelGGL(k_accumulate, dim3(stream_blocks), dim3(kBlock), 0, sm, p, wf.Lsum, r->accum);
             stage_end(r, sm);
-            if (read_dst && row1 > row0) {
+            if (read && row1 > row0) {
                 // these pixel rows are final: their read-back overlaps the wavefronts that are still tracing the other rows
                 const size_t off = (size_t)row0 * r->w, cnt = (size_t)(row1 - row0) * r->w;
-                hipLaunchKernelGGL(k_resolve, dim3(div_up((uint32_t)cnt, kBlock)), dim3(kBlock), 0, sm, r->accum + off, r->scratch + off, (uint32_t)cnt);
-                HIP_TRY(hipMemcpyAsync(read_dst + 4u * off, r->scratch + off, sizeof(float4) * cnt, hipMemcpyDeviceToHost, sm));
+                if (read->radiance) {
+                    hipLaunchKernelGGL(k_resolve, dim3(div_up((uint32_t)cnt, kBlock)), dim3(kBlock), 0, sm, r->accum + off, r->scratch + off, (uint32_t)cnt);
+                    HIP_TRY(hipMemcpyAsync(read->radiance + 4u * off, r->scratch + off, sizeof(float4) * cnt, hipMemcpyDeviceToHost, sm));
+                } else {
+                    uchar4 *px = reinterpret_cast<uchar4 *>(r->scratch) + off;
+                    hipLaunchKernelGGL(k_tonemap, dim3(div_up((uint32_t)cnt, kBlock)), dim3(kBlock), 0, sm, r->accum + off, px, (uint32_t)cnt, r->srgb_thr);
+                    HIP_TRY(hipMemcpy2DAsync(read->rgba8 + (size_t)row0 * read->row_bytes, read->row_bytes, px, (size_t)r->w * 4, (size_t)r->w * 4, row1 - row0, hipMemcpyDeviceToHost, sm));
+                }
             }
         } else {
             // per-pixel filter inputs; on a sharded frame (world > 1) the caller now exchanges noisy / gbuffer / motion
@@ -1609,8 +1621,8 @@ static int wavefront_finish(lpt_renderer *r, const Ticket &tk, float *read_dst, 
 // frame leave as two wavefronts of 4.1 M rays (the upper and the lower half of the image), the shading of one overlaps the
 // traversal of the other (measured for two 4 M-ray wavefronts: 13.30 ms per frame against 13.68 for one 8 M-ray wavefront and
 // 14.1 for four 2 M-ray ones), and the piece that was launched first is complete about one stage before the last:
-// `read_dst` (lpt_renderer_read_radiance) has every piece's rows copied to the host as soon as they are final.
-static int flush_pending(lpt_renderer *r, float *read_dst) {
+// `read` (lpt_renderer_read_radiance, lpt_renderer_blit_rgba8) has every piece's rows copied to the host as soon as they are final.
+static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
     if (!r->pend.n) return LPT_OK;
     const lpt_renderer::Pending b = r->pend;
     r->pend.n = 0;
@@ -1633,14 +1645,14 @@ static int flush_pending(lpt_renderer *r, float *read_dst) {
         return st != LPT_OK ? st : wavefront_finish(r, tk[0], nullptr, 0u, 0u);
     }
     // The first halves run ahead of the second halves by the number of lanes: wavefront k's launches are enqueued before the
-    // renderer's stream is given the accumulation (and the read-back copy, which blocks the host when `read_dst` is pageable
+    // renderer's stream is given the accumulation (and the read-back copy, which blocks the host when the destination is pageable
     // memory) of wavefront k - lanes — the wavefront that used the same lane, whose buffers k overwrites.
-    const bool early = read_dst && whole_rows && r->mode == LPT_BLIT_PATHTRACE;
+    const bool early = read && whole_rows && r->mode == LPT_BLIT_PATHTRACE;
     const uint32_t ahead = (r->mode != LPT_BLIT_PATHTRACE || r->n_lanes < 2) ? 1u : (uint32_t)r->n_lanes;
     const uint32_t pieces = div_up(granules, per_piece);
     auto finish = [&](uint32_t k) {
         const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
-        return wavefront_finish(r, tk[k % ahead], early ? read_dst : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
+        return wavefront_finish(r, tk[k % ahead], early ? read : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
     };
     for (uint32_t k = 0; k < pieces; ++k) {
         if (k >= ahead) { const int st = finish(k - ahead); if (st != LPT_OK) return st; }
@@ -1755,7 +1767,9 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
         // the frame is still recorded: submit it with its own read-back — every wavefront's pixel rows travel to the host as
         // soon as they are final, under the wavefronts that are still tracing (the recorded calls clear `presented`, so the
         // local target is what is shown)
-        const int st = flush_pending(r, dst);
+        ReadPlan plan;
+        plan.radiance = dst;
+        const int st = flush_pending(r, &plan);
         if (st != LPT_OK) return st;
         const hipError_t se = hipStreamSynchronize(r->stream);
         if (se != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(se));
@@ -1784,6 +1798,16 @@ int lpt_host_free(void *ptr) {
 
 int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
     if (!r || !dst || row_bytes < (size_t)r->w * 4) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_blit_rgba8: bad arguments");
+    if (r->pend.n && r->accum && r->world == 1u && r->mode == LPT_BLIT_PATHTRACE) {
+        // the frame is still recorded: submit it with its own read-back, piece by piece (lpt_renderer_read_radiance does the same)
+        ReadPlan plan;
+        plan.rgba8 = dst; plan.row_bytes = row_bytes;
+        const int st = flush_pending(r, &plan);
+        if (st != LPT_OK) return st;
+        const hipError_t se = hipStreamSynchronize(r->stream);
+        if (se != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(se));
+        return LPT_OK;
+    }
     FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
     hipError_t e = hipSetDevice(r->dev->ordinal);

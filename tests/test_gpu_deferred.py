@@ -223,3 +223,35 @@ def test_the_cut_frame_equals_the_oracle_and_explicit_batches_stay_whole(device,
     assert whole.submission_stats() == (4, 1, 0)
     assert whole.read_radiance().tobytes() == ref.tobytes()
     whole.close()
+
+
+@pytest.mark.parametrize("size,lanes", [((203, 117), 2), ((256, 128), 1)])
+def test_read_pixels_and_blit_of_a_recorded_frame_travel_piece_by_piece_too(device, cornell, monkeypatch, size, lanes):
+    """read_pixels (Renderer::read_pixels, renderer.rs:727-811) / blit on a still recorded frame: every wavefront's rows are tonemapped
+    and copied behind its own accumulation, also into a destination with padded rows — byte for byte the ordinary path's image"""
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    w, h = size
+    ref = _renderer(device, sg, pr, 1, size=size)
+    for _ in range(4):
+        ref.raytrace(view)
+    want = ref.read_pixels()
+    for how in ("read_pixels", "blit", "blit_padded"):
+        cut = _cut_renderer(device, sg, pr, monkeypatch, 3 * 256 * -(-w // 32) * 4, size, lanes)
+        for _ in range(4):
+            cut.raytrace(view)
+        assert cut.submission_stats() == (4, 0, 4)
+        if how == "read_pixels":
+            got = cut.read_pixels()
+        elif how == "blit":
+            got = cut.blit()
+        else:
+            pitch = w * 4 + 52
+            buf = cut.blit(row_bytes=pitch)
+            assert not buf[:, w * 4:].any()                  # the padding of every row is untouched
+            got = buf[:, :w * 4].reshape(h, w, 4)
+        assert cut.submission_stats()[1] > 1 and cut.submission_stats()[2] == 0
+        assert got.tobytes() == want.tobytes(), how
+        assert cut.read_pixels().tobytes() == want.tobytes()   # nothing recorded: the ordinary path
+        cut.close()
+    ref.close()
