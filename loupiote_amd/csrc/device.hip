@@ -4,7 +4,7 @@
 // (reference crates/lib/src/renderer.rs:392-549): pass order, the seed / bounces /
 // frame_count protocol and the accumulate flag.  raytrace() RECORDS (the reference records into an encoder the app submits
 // once, app.rs:335-337); a submission point launches the recorded calls as wavefronts of several samples per pixel
-// (record_call / flush_pending / submit_wavefront).  A renderer enqueues on its own HIP stream (accumulation,
+// (record_call / flush_pending / wavefront_trace + wavefront_finish).  A renderer enqueues on its own HIP stream (accumulation,
 // filter passes, reads, the frame exchange: in call order) and on the streams of its wavefront lanes (the
 // traversal / shading of consecutive wavefronts, overlapped); nothing here waits for the GPU except the
 // read-back calls (the reference's only blocking point is read_pixels, :791) and scene edits.
