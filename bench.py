@@ -421,7 +421,7 @@ def run(args):
     slowest_frame = max(range(len(frame_ms)), key=lambda i: frame_ms[i]) if frame_ms else -1
     frame_ms.sort()
     c_ = r.ray_counts()
-    closest_l, shadow_l, shaded_l = c_.closest, c_.shadow, c_.shaded
+    closest_l, shadow_l, shaded_l, primary_l = c_.closest, c_.shadow, c_.shaded, c_.primary
     n_frames = args.steps * FPS
     # the per-stage breakdown (and the exchange time) comes from FPS more frames of the same loop with the library's event timing on:
     # two hipEventRecord per launch delay the second wavefront's launches by ~0.1 ms per frame, so the timed region runs without them
@@ -465,8 +465,13 @@ def run(args):
     fence([r])
     st = r.ray_counts()
     r.enable_stats(False)
-    n_bar = st.nodes / max(st.closest, 1)
-    t_bar = st.tris / max(st.closest, 1)
+    # bounce 0 is traced by packet traversal (k_trace_packet: one tree walk per 64 coherent rays) — another kernel, with its own
+    # counters; `nodes` / `tris` are k_trace's, per closest-hit ray of the bounces it traces
+    kt_closest = st.closest - st.primary
+    n_bar = st.nodes / max(kt_closest, 1)
+    t_bar = st.tris / max(kt_closest, 1)
+    packets_stat = max(st.primary / 64.0, 1.0)
+    pk_nodes, pk_tris = st.packet_nodes / packets_stat, st.packet_tris / packets_stat
     ns_bar = st.shadow_nodes / max(st.shadow, 1)
     ts_bar = st.shadow_tris / max(st.shadow, 1)
     accel = sg.stats()
@@ -485,7 +490,7 @@ def run(args):
     # shares the chip.  The kernel figure (roofline.frac) is taken from SOLO_FRAMES frames issued as ONE wavefront each
     # (lpt_renderer_set_max_fused(spp)), one frame at a time: un-overlapped launches, HIP events on the stream they run on.
     SOLO_FRAMES = 3
-    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, closest_l / n_frames * FPS, shadow_l / n_frames * FPS)
+    o_avg, o_launches, o_bytes, o_achieved = trace_stage(timings, (closest_l - primary_l) / n_frames * FPS, shadow_l / n_frames * FPS)
     r.set_max_fused(max(SPP, 1))
     span_frame()                       # the lanes' ray buffers grow to the batch size on first use
     fence([r])
@@ -498,8 +503,17 @@ def run(args):
     r.enable_timings(False)
     sc_ = r.ray_counts()
     r.set_max_fused(args.max_fused)
-    s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest, sc_.shadow)
-    rays_per_launch = (sc_.closest + sc_.shadow) / max(s_launches, 1)
+    s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest - sc_.primary, sc_.shadow)
+    rays_per_launch = (sc_.closest - sc_.primary + sc_.shadow) / max(s_launches, 1)
+    pk_ms, pk_launches = solo_t.get("primary intersection", (0.0, 0))
+    packet_j = None
+    if pk_launches:
+        pk_avg = pk_ms / pk_launches
+        pk_bytes = 32.0 * 64 + 16.0 * 64 + pk_nodes * accel.node_bytes + pk_tris * accel.tri_bytes      # per packet: 64 rays read, 64 hits written, the nodes / triangles once
+        packet_j = {"kernel": "k_trace_packet", "what": "bounce 0: one tree walk per 64 coherent primary rays (an 8x8-pixel patch of one sample), node and triangle fetches by scalar loads",
+                    "avg_launch_ms": pk_avg, "launches": pk_launches, "rays_per_launch": sc_.primary / pk_launches, "Mrays_per_s": sc_.primary / pk_launches / (pk_avg * 1e-3) / 1e6,
+                    "nodes_per_packet": pk_nodes, "tris_per_packet": pk_tris, "bytes_per_packet": pk_bytes,
+                    "achieved_GBps": sc_.primary / 64.0 / pk_launches * pk_bytes / (pk_avg * 1e-3) / 1e9}
     exchange_ms = timings.get("exchange", (0.0, 0))
 
     # ---- the read-back alone: k_resolve + 33 MB device -> host of an already finished frame (depends on the box's PCIe link and host)
@@ -581,7 +595,7 @@ def run(args):
         if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
-        o_avg, o_launches, o_bytes, o_achieved = trace_stage(tm, closest_l / n_frames * T_STEPS * FPS, shadow_l / n_frames * T_STEPS * FPS)
+        o_avg, o_launches, o_bytes, o_achieved = trace_stage(tm, (closest_l - primary_l) / n_frames * T_STEPS * FPS, shadow_l / n_frames * T_STEPS * FPS)
         throughput = {"value": float(tr.item()) / float(tt.item()) / 1e6, "unit": "Mrays/s", "ms_per_frame": float(tt.item()) / (T_STEPS * FPS) * 1e3,
                       "frames": T_STEPS * FPS, "frames_in_flight": P, "communicators": P if comms else 0,
                       "what": "%d renderers take the frames in turn (own HIP streams%s); frame = reset_accumulation + raytrace_n(view, 4)%s; no read-back — "
@@ -650,7 +664,7 @@ def run(args):
                          "timed_region": {"achieved": o_achieved, "frac": o_achieved / HBM_PEAK_GBS, "avg_launch_ms": o_avg, "launches": o_launches, "bytes_per_launch": o_bytes,
                                           "note": "the same over the timed region, where the two 4-sample half-frame wavefronts of a frame overlap on the renderer's lanes: a launch shares "
                                                   "the chip with the other wavefront's kernels — a scheduling figure, not a kernel figure"},
-                         "region": {"achieved": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": (closest_l * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "region": {"achieved": ((closest_l - primary_l) * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": ((closest_l - primary_l) * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
                                     "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation, the read-back): a lower bound"},
                          "limits": limits_j,
                          "binding_limit": ({"name": "vector_memory_path", "frac": limits_j["gather_path"]["frac_of_9.7"], "frac_range": [limits_j["gather_path"]["frac_of_13.5"], limits_j["gather_path"]["frac_of_9.7"]],
@@ -663,7 +677,8 @@ def run(args):
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
-                                  "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(st.closest, 1)}},
+                                  "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(kt_closest, 1)},
+                         "packet": packet_j},
             "stage_ms_per_frame": {k: v[0] / FPS for k, v in timings.items()},
             "stage_ms_per_frame_solo": {k: v[0] / SOLO_FRAMES for k, v in solo_t.items()},
             "accel": {"triangles": accel.triangles, "nodes": accel.nodes, "node_bytes": accel.node_bytes,

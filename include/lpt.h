@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LPT_ABI_VERSION 3u
+#define LPT_ABI_VERSION 4u
 
 /* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
 #define LPT_INVALID_INDEX 0xFFFFFFFFu
@@ -138,10 +138,15 @@ typedef struct lpt_ray_counts {
     uint64_t live_lanes;   /* lanes carrying a ray, summed over those iterations        */
     uint64_t node_lanes;   /* lanes that entered the node test                         */
     uint64_t tri_lanes;    /* lanes that ran a triangle test                           */
+    /* ABI 4: bounce 0 is traced by packet traversal (one tree walk per 64 coherent rays): these rays are part of `closest`, their
+     * node / triangle fetches are NOT part of `nodes` / `tris` */
+    uint64_t primary;      /* closest-hit rays traced as packets                               */
+    uint64_t packet_nodes; /* nodes entered, once per PACKET (stats enabled only)              */
+    uint64_t packet_tris;  /* triangles fetched, once per PACKET (stats enabled only)          */
 } lpt_ray_counts;
 
 typedef struct lpt_timing {
-    char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation" */
+    char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection" */
     float ms;       /* summed over every raytrace() since enable_timings(1) */
     uint32_t launches;
 } lpt_timing;

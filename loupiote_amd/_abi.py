@@ -47,7 +47,7 @@ class AccelStats(C.Structure):
 
 class RayCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris", "shadow_nodes", "shadow_tris",
-                                             "wave_steps", "live_lanes", "node_lanes", "tri_lanes")]
+                                             "wave_steps", "live_lanes", "node_lanes", "tri_lanes", "primary", "packet_nodes", "packet_tris")]
 
 
 class Timing(C.Structure):

@@ -137,8 +137,10 @@ struct lpt_probe {
     void *rgbe = nullptr;
 };
 
-enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_EXCHANGE, ST_COUNT };
-static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange"};
+enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_EXCHANGE, ST_PRIMARY, ST_COUNT };
+// "primary intersection": the IntersectorPass of bounce 0 when it runs as packet traversal (k_trace_packet), timed apart from the
+// per-ray traversal launches ("intersection") because it is another kernel
+static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection"};
 
 // One independent wavefront context ("lane") of a renderer: everything a raytrace() call owns while its rays are in flight.
 // Consecutive raytrace() calls of ONE renderer take the lanes in turn (default 2), so the traversal / shading of call k+1
@@ -182,6 +184,7 @@ struct lpt_renderer {
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
     uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
                                // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
+    bool packet_primary = true;    // bounce 0 by packet traversal (k_trace_packet); LPT_PACKET=0: per-ray traversal like every other bounce
     uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_PIPE_RAYS=0: none
     uint64_t wavefront_rays = kWavefrontRays;   // LPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
     uint64_t n_recorded = 0, n_wavefronts = 0;   // raytrace() calls recorded / wavefronts submitted so far (lpt_renderer_get_submission_stats)
@@ -1096,6 +1099,7 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     if (const char *ev = getenv("LPT_SORT")) r->sort_queues = atoi(ev) & 3;
     if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
     if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
+    if (const char *ev = getenv("LPT_PACKET")) r->packet_primary = atoi(ev) != 0;
     if (const char *ev = getenv("LPT_PIPE_RAYS")) r->pipe_rays = (uint32_t)std::max(0ll, std::min(0x7FFFFFFFll, atoll(ev)));
     if (const char *ev = getenv("LPT_WAVEFRONT_RAYS")) r->wavefront_rays = (uint64_t)std::max(64ll, atoll(ev));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
@@ -1410,7 +1414,7 @@ extern "C" {
 struct Ticket {
     FrameParams p;
     int lane = 0;
-    bool split = false, denoise = false;
+    bool split = false, denoise = false, packet = false;
     CamBasis cur{};
 };
 
@@ -1438,6 +1442,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
     p.map = r->map;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
     p.slot0 = slot0;
+    p.block8 = (r->tile_w % 8u == 0u && r->tile_h % 8u == 0u) ? 1u : 0u;
     p.n_slots = piece_slots;                     // the slots of THIS wavefront
     p.frame_count = frame_count0;
     p.max_bounces = nb;
@@ -1519,6 +1524,8 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         }
         stage_end(r, s);
 
+        const bool packet = r->packet_primary && r->merge_trace;
+        tk.packet = packet;
         uint32_t seed = seed0;
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
         // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
@@ -1533,7 +1540,17 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
             stage_end(r, s);
         };
-        if (r->merge_trace) trace(0, -1);
+        if (r->merge_trace) {
+            if (packet) {
+                // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
+                stage_begin(r, ST_PRIMARY, s);
+                const uint32_t packets = div_up(n_rays, 64u);
+                const size_t plds = (size_t)(7u * r->sg->stats.max_depth + 8u) * sizeof(uint32_t);
+                if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
+                else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
+                stage_end(r, s);
+            } else trace(0, -1);
+        }
         for (uint32_t b = 0; b < nb; ++b) {
             seed += 1u;                          // :453, :487
             const Queue qin = wf.q[b & 1u], qout = wf.q[(b + 1u) & 1u];
@@ -1603,7 +1620,7 @@ static int wavefront_finish(lpt_renderer *r, const Ticket &tk, const ReadPlan *r
             if (r->world == 1u) launch_filter(r, sm);
             stage_end(r, sm);
         }  // GBuffer / MotionVector: the primary pass has written the debug targets; nothing else runs (:539)
-        hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, sm, wf.ctr, r->totals, nb);
+        hipLaunchKernelGGL(k_finish_frame, dim3(1), dim3(64), 0, sm, wf.ctr, r->totals, nb, tk.packet ? 1u : 0u);
         if (split) {
             HIP_TRY(hipEventRecord(wf.consumed, sm));
             wf.consumed_recorded = true;
@@ -1887,6 +1904,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     out->closest = t.closest; out->shadow = t.shadow; out->shaded = t.shaded; out->nodes = t.nodes; out->tris = t.tris;
     out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
     out->wave_steps = t.wave_steps; out->live_lanes = t.live_lanes; out->node_lanes = t.node_lanes; out->tri_lanes = t.tri_lanes;
+    out->primary = t.primary; out->packet_nodes = t.packet_nodes; out->packet_tris = t.packet_tris;
     return LPT_OK;
 }
 
@@ -2039,6 +2057,7 @@ static FrameParams shard_params(const lpt_renderer *r) {
     p.width = r->w; p.height = r->h;
     p.rank = r->rank; p.world = r->world; p.tile_w = r->tile_w; p.tile_h = r->tile_h;
     p.map = r->map;
+    p.block8 = (r->tile_w % 8u == 0u && r->tile_h % 8u == 0u) ? 1u : 0u;
     shard_geometry(r, p.tiles_x, p.n_tiles, p.n_slots);
     return p;
 }

@@ -73,8 +73,10 @@ struct FrameCounters {
     uint32_t shaded[kMaxBounces];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
     unsigned long long wave_steps, live_lanes, node_lanes, tri_lanes;  // closest-hit kernel, stats only
+    unsigned long long packet_nodes, packet_tris;   // k_trace_packet, stats only: nodes entered / triangles tested per PACKET, summed
 };
-struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes; };
+struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes,
+                                   primary, packet_nodes, packet_tris; };   // mirrors lpt_ray_counts
 
 // Tile ownership.  Tile t (row-major over the tile grid) belongs to VIRTUAL rank t % V; the V virtual ranks are dealt to
 // the ranks in proportion to their weights (a rank that also assembles, reads back or filters the frame gets fewer tiles).  With
@@ -105,6 +107,10 @@ struct FrameParams {
     // spatially): n_slots = the slots of this wavefront, slot0 = the first of them among the rank's slots.  Everything inside a
     // wavefront (queues, Lsum) is indexed by the local slot; only the slot -> pixel map needs slot0
     uint32_t slot0;
+    // pixels inside a tile: in 8x8 blocks (block after block along the tile's rows, row-major inside a block) when both tile sides
+    // are multiples of 8 — 64 consecutive slots are then a SQUARE patch of the image, the most coherent packet of primary rays
+    // (k_trace_packet) — else row-major over the whole tile
+    uint32_t block8;
     uint32_t frame_count, max_bounces;
     // batched samples (lpt_renderer_raytrace_n): sample k of the batch behaves like the k-th of n
     // consecutive raytrace() calls: seeds advance by max_bounces per sample, frame_count by fc_inc0
@@ -121,6 +127,21 @@ __device__ __forceinline__ void st_nt(float4 *p, const float4 v) { const f4v w =
 // pixel slot -> pixel.  Slots enumerate this rank's tiles in ascending tile id (period after period of V tiles, the rank's
 // virtual ranks inside a period; with unit weights: tile ids rank, rank+world, ...) and the pixels inside each tile row-major,
 // so a wave64 covers a 32x2 pixel block.
+__device__ __forceinline__ void within_to_xy(const FrameParams &p, uint32_t within, uint32_t &wx, uint32_t &wy) {
+    if (p.block8) {
+        const uint32_t block = within >> 6, in = within & 63u, per_row = p.tile_w >> 3;
+        const uint32_t by = block / per_row, bx = block - by * per_row;
+        wx = bx * 8u + (in & 7u);
+        wy = by * 8u + (in >> 3);
+    } else {
+        wy = within / p.tile_w;
+        wx = within - wy * p.tile_w;
+    }
+}
+__device__ __forceinline__ uint32_t xy_to_within(const FrameParams &p, uint32_t wx, uint32_t wy) {
+    if (p.block8) return (((wy >> 3) * (p.tile_w >> 3) + (wx >> 3)) << 6) + ((wy & 7u) << 3) + (wx & 7u);
+    return wy * p.tile_w + wx;
+}
 __device__ __forceinline__ bool slot_to_pixel(const FrameParams &p, uint32_t slot, uint32_t &x, uint32_t &y) {
     const uint32_t per_tile = p.tile_w * p.tile_h;
     const uint32_t k = slot / per_tile, within = slot - k * per_tile;
@@ -134,7 +155,8 @@ __device__ __forceinline__ bool slot_to_pixel(const FrameParams &p, uint32_t slo
     const uint32_t tile = period * p.map.V + v;
     if (tile >= p.n_tiles) return false;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    const uint32_t wy = within / p.tile_w, wx = within - wy * p.tile_w;
+    uint32_t wx, wy;
+    within_to_xy(p, within, wx, wy);
     x = tx * p.tile_w + wx;
     y = ty * p.tile_h + wy;
     return x < p.width && y < p.height;
@@ -728,6 +750,142 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     }
 }
 
+// five / three consecutive 16-byte scalar loads from a wave-uniform address (the compiler keeps uniform loads of memory it cannot
+// prove unwritten on the vector path: 64 lanes fetching one address)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sload_node(const void *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d, uint4 &e) {
+    u32x4 va, vb, vc, vd, ve;
+    asm volatile("s_load_dwordx4 %0, %5, 0x0\n\ts_load_dwordx4 %1, %5, 0x10\n\ts_load_dwordx4 %2, %5, 0x20\n\t"
+                 "s_load_dwordx4 %3, %5, 0x30\n\ts_load_dwordx4 %4, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(va), "=&s"(vb), "=&s"(vc), "=&s"(vd), "=&s"(ve) : "s"(p) : "memory");
+    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w); c = make_uint4(vc.x, vc.y, vc.z, vc.w);
+    d = make_uint4(vd.x, vd.y, vd.z, vd.w); e = make_uint4(ve.x, ve.y, ve.z, ve.w);
+}
+__device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, float4 &c) {
+    u32x4 va, vb, vc;
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(va), "=&s"(vb), "=&s"(vc) : "s"(p) : "memory");
+    a = make_float4(__uint_as_float(va.x), __uint_as_float(va.y), __uint_as_float(va.z), __uint_as_float(va.w));
+    b = make_float4(__uint_as_float(vb.x), __uint_as_float(vb.y), __uint_as_float(vb.z), __uint_as_float(vb.w));
+    c = make_float4(__uint_as_float(vc.x), __uint_as_float(vc.y), __uint_as_float(vc.z), __uint_as_float(vc.w));
+}
+
+// Closest hits of COHERENT rays — the primary rays of bounce 0, 64 consecutive queue entries = one 8x8-pixel patch of one sample —
+// by packet traversal: the wave walks the tree ONCE for its 64 rays.  The node (and every triangle) a step looks at is the same for
+// all lanes, so it is fetched with scalar loads, once per wave instead of once per lane; every lane tests its own ray against it.
+// A child is entered when ANY lane's clipped interval [0, its best hit] meets the child's box; every lane tests every triangle of an
+// entered leaf.  A lane therefore tests a superset of the triangles its own traversal would, and only the Woop test decides: the
+// hits are those of k_trace bit for bit (closest hit, ties to the lower primitive id: order-independent).  On the bench scene an
+// 8x8 packet enters 17.5 nodes and tests 11.7 triangles where ONE of its rays alone enters 14.9 and tests 3.6 (tools/dev/packet_probe.cpp).
+// The wave's stack (node indices) is one LDS column per wave.  Works for any rays; it only pays for coherent ones.
+template <bool STATS>
+__global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // 7 siblings per level + the path: (7 * depth + 8) entries (host)
+    // read-only for the whole launch and never aliased by what the kernel writes: lets the uniform fetches below become scalar loads
+    const DNode8 *__restrict__ nodes = sc.nodes;
+    const float4 *__restrict__ woop = sc.woop;
+    const uint32_t *__restrict__ leaf_prim = sc.leaf_prim;
+    const uint32_t count = ctr->qcount[bounce];
+    const uint32_t lane = threadIdx.x;
+    uint32_t visits = 0, tests = 0;
+    for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
+        const uint32_t ray = base + lane;
+        const bool live = ray < count;
+        f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+        if (live) { const float4 o4 = q.o[ray], d4 = q.d[ray]; o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z); }
+        const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+        const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+        Hit best;
+        best.t = live ? LPT_T_INF : 0.0f; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;   // a dead lane's interval [0, 0] meets nothing
+        // visit order: the first lane's octant stands for the packet
+        const uint32_t oinv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(7u - ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u))));
+        int sp = 0;
+        uint32_t node_index = 0;
+        bool have = true;
+        while (have) {
+            uint4 n0, n1, n2, n3, n4;
+            sload_node(nodes + node_index, n0, n1, n2, n3, n4);   // wave-uniform address
+            if (STATS) visits++;
+            const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
+            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
+            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
+            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
+            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
+            const float by = (__uint_as_float(n0.y) - o.y) * iy;
+            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+            const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
+            const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
+            const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
+            const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
+            const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
+            const float tbest = best.t;
+            uint32_t entered = 0u;   // wave-uniform: slots some lane's ray enters
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
+                const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sh = 8 * j;
+                    const float qlx = (float)((lox >> sh) & 0xFFu), qhx = (float)((hix >> sh) & 0xFFu);   // uniform conversions
+                    const float qly = (float)((loy >> sh) & 0xFFu), qhy = (float)((hiy >> sh) & 0xFFu);
+                    const float qlz = (float)((loz >> sh) & 0xFFu), qhz = (float)((hiz >> sh) & 0xFFu);
+                    const float tnx = fmaf(negx ? qhx : qlx, ax, bnx), tfx = fmaf(negx ? qlx : qhx, ax, bfx);
+                    const float tny = fmaf(negy ? qhy : qly, ay, bny), tfy = fmaf(negy ? qly : qhy, ay, bfy);
+                    const float tnz = fmaf(negz ? qhz : qlz, az, bnz), tfz = fmaf(negz ? qlz : qhz, az, bfz);
+                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
+                    if (__ballot(tn <= tf) != 0ull) entered |= 1u << (4 * half + j);
+                }
+            }
+            // empty slots have inverted boxes (lo 255, hi 0) and are never entered
+            const uint32_t imask = n0.w >> 24;
+            // leaves first: every lane tests every triangle of an entered leaf slot
+            uint32_t leaves = entered & ~imask;
+            while (leaves) {
+                const uint32_t sl = (uint32_t)__ffs((int)leaves) - 1u;
+                leaves &= leaves - 1u;
+                const uint32_t meta = ((sl < 4u ? n1.z : n1.w) >> (8u * (sl & 3u))) & 0xFFu;
+                uint32_t bits = meta >> 5;
+                const uint32_t first = n1.y + (meta & 31u);
+                for (uint32_t k = 0; bits; ++k, bits >>= 1) {
+                    if (!(bits & 1u)) continue;
+                    const uint32_t ti = first + k;
+                    float4 r0, r1, r2;
+                    sload_tri(woop + 3u * (size_t)ti, r0, r1, r2);
+                    if (STATS) tests++;
+                    float t, u, v;
+                    if (ray_triangle(r0, r1, r2, o, d, best.t, t, u, v)) {
+                        const uint32_t prim = leaf_prim[ti];
+                        if (t < best.t || prim < best.prim) { best.t = t; best.u = u; best.v = v; best.prim = prim; }
+                    }
+                }
+            }
+            // inner children: pushed so that the one nearest along the packet's octant order pops first
+            // (k_trace takes bit 24 + (slot ^ oinv) from the top: the largest slot ^ oinv first)
+            uint32_t inner = entered & imask;
+            uint32_t keyed = 0u;   // bit (slot ^ oinv) set for every entered inner slot
+            for (uint32_t m = inner; m; m &= m - 1u) keyed |= 1u << (((uint32_t)__ffs((int)m) - 1u) ^ oinv);
+            for (uint32_t m = keyed; m; m &= m - 1u) {   // ascending key: the largest key is pushed last and pops first
+                const uint32_t sl = ((uint32_t)__ffs((int)m) - 1u) ^ oinv;
+                const uint32_t rel = (uint32_t)__popc(imask & ~(0xFFFFFFFFu << sl));
+                if (lane == 0) stk[sp] = n1.x + rel;
+                sp++;
+            }
+            have = sp > 0;
+            if (have) { sp--; node_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[sp]); }
+        }
+        if (live) {
+            intersect_lights(sc, o, d, best);
+            st_nt(hits + ray, make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)));
+        }
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&ctr->packet_nodes, (unsigned long long)visits);
+        atomicAdd(&ctr->packet_tris, (unsigned long long)tests);
+    }
+}
+
 // stand-alone closest-hit query (lpt_trace_closest): one ray per lane, no refill
 __global__ __launch_bounds__(kTraceBlock) void k_query_closest(DScene sc, const float4 *o, const float4 *d, float4 *hits, uint32_t n) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
@@ -1138,7 +1296,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const Sh
         const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
         uint32_t owner, slot0;
         tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
-        const uint32_t slot = slot0 + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        const uint32_t slot = slot0 + xy_to_within(p, x - tx * p.tile_w, y - ty * p.tile_h);
         frame[i] = staged[(size_t)st.offset[owner] + slot];
     }
 }
@@ -1168,7 +1326,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_den(FrameParams p, const Shar
         const uint32_t ty = y / p.tile_h, tx = x / p.tile_w;
         uint32_t owner, slot0;
         tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
-        const uint32_t slot = slot0 + (y - ty * p.tile_h) * p.tile_w + (x - tx * p.tile_w);
+        const uint32_t slot = slot0 + xy_to_within(p, x - tx * p.tile_w, y - ty * p.tile_h);
         const uint32_t first = st.offset[owner];
         const size_t n_owner = st.offset[owner + 1u] - first;
         const unsigned char *base = staged + 40u * (size_t)first;
@@ -1307,8 +1465,9 @@ __global__ __launch_bounds__(kBlock) void k_debug_view(const uint4 *gb, const fl
     }
 }
 
-__global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces) {
+__global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces, uint32_t packet_primary) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (packet_primary) { tot->primary += ctr->qcount[0]; tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
     unsigned long long c = 0, s = 0, sh = 0;
     for (uint32_t b = 0; b < bounces; ++b) { c += ctr->qcount[b]; s += ctr->shcount[b]; sh += ctr->shaded[b]; }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;

@@ -120,13 +120,17 @@ def test_owner_map_properties():
 # library (lpt_shard_layout: pure host arithmetic, callable without a GPU); the slot <-> pixel rule is restated here
 # from kernels.h (slot_to_pixel / k_pack_owned / k_unpack_frame), the send / recv pairs become one gloo gather.
 def _slot_pixels(w, h, rank, world, tw, th):
-    """pixel index of every slot of `rank` (tile after owned tile, row-major inside a tile), -1 outside the image"""
+    """pixel index of every slot of `rank`, -1 outside the image: tile after owned tile; inside a tile in 8x8 blocks (block after
+    block along the tile's rows, row-major inside a block) when both tile sides are multiples of 8, else row-major (kernels.h
+    within_to_xy)"""
     tiles_x, tiles_y = (w + tw - 1) // tw, (h + th - 1) // th
     out = []
     for tile in range(rank, tiles_x * tiles_y, world):
         ty, tx = divmod(tile, tiles_x)
         ys, xs = np.mgrid[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
         px = np.where((xs < w) & (ys < h), ys * w + xs, -1)
+        if tw % 8 == 0 and th % 8 == 0:
+            px = px.reshape(th // 8, 8, tw // 8, 8).transpose(0, 2, 1, 3)   # (block row, block column, y in block, x in block)
         out.append(px.reshape(-1))
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 

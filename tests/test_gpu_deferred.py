@@ -259,12 +259,13 @@ def test_read_pixels_and_blit_of_a_recorded_frame_travel_piece_by_piece_too(devi
 
 def test_both_traversal_steps_give_the_oracle_frame(device, cornell, cornell_glb, monkeypatch):
     """k_trace's default step makes one memory round trip (kernels.h ray_step_pipe: the triangle tested in a step was found by an
-    earlier one); LPT_PIPE_RAYS=0 selects the two-round-trip step, LPT_MERGE_TRACE=0 the split k_intersect / k_shadow launches.
-    The order of the tests differs, the frame and the ray counts do not."""
+    earlier one) and bounce 0 is traced by packet traversal (k_trace_packet: one tree walk per 64 coherent rays); LPT_PIPE_RAYS=0
+    selects the two-round-trip step, LPT_PACKET=0 per-ray traversal for bounce 0 too, LPT_MERGE_TRACE=0 the split k_intersect /
+    k_shadow launches.  The order of the tests differs, the frame and the ray counts do not."""
     _, sg, pr = cornell
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
-    for env in ({}, {"LPT_PIPE_RAYS": "0"}, {"LPT_PIPE_RAYS": "30000"}, {"LPT_MERGE_TRACE": "0"}):
+    for env in ({}, {"LPT_PIPE_RAYS": "0"}, {"LPT_PIPE_RAYS": "30000"}, {"LPT_MERGE_TRACE": "0"}, {"LPT_PACKET": "0"}, {"LPT_PACKET": "0", "LPT_PIPE_RAYS": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         r = _renderer(device, sg, pr, 0)
@@ -275,4 +276,5 @@ def test_both_traversal_steps_give_the_oracle_frame(device, cornell, cornell_glb
         assert r.read_radiance().tobytes() == ref.tobytes(), env
         c = r.ray_counts()
         assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded), env
+        assert c.primary == (0 if ("LPT_PACKET" in env or "LPT_MERGE_TRACE" in env) else 4 * W * H), env   # which kernel traced bounce 0
         r.close()
