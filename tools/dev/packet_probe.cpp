@@ -169,6 +169,100 @@ void walk_packet(const Accel &a, const std::vector<std::array<float,3>> &O, cons
     }
 }
 
+// any-hit of ONE ray within [0, tmax]: nodes entered until the first hit (k_trace's shadow rays)
+bool walk_any(const Accel &a, const float o[3], const float d[3], float tmax, uint64_t &nodes, uint64_t &tris) {
+    Hit best; best.t = tmax;
+    const float inv[3] = {safe_inv(d[0]), safe_inv(d[1]), safe_inv(d[2])};
+    const uint32_t oinv = 7u - ((inv[0] < 0 ? 1u : 0u) | (inv[1] < 0 ? 2u : 0u) | (inv[2] < 0 ? 4u : 0u));
+    std::vector<uint32_t> stack{0};
+    while (!stack.empty()) {
+        const uint32_t ni = stack.back(); stack.pop_back();
+        const Node8 &n = a.nodes[ni];
+        nodes++;
+        const uint8_t ebytes[3] = {n.ex, n.ey, n.ez};
+        const float p[3] = {n.px, n.py, n.pz};
+        const uint8_t *qlo[3] = {n.qlox, n.qloy, n.qloz}, *qhi[3] = {n.qhix, n.qhiy, n.qhiz};
+        struct Child { uint32_t key, node; };
+        Child inner[8]; int n_inner = 0; uint32_t rel = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            const uint8_t meta = n.meta[sl];
+            const bool is_inner = (n.imask >> sl) & 1u;
+            const uint32_t my_rel = rel;
+            if (is_inner) rel++;
+            if (!meta) continue;
+            float tn = 0.0f, tf = best.t;
+            for (int k = 0; k < 3; ++k) {
+                uint32_t bits = (uint32_t)ebytes[k] << 23; float scale; memcpy(&scale, &bits, 4);
+                const float A = scale * inv[k], B = (p[k] - o[k]) * inv[k];
+                const float E = fmaf(fabsf(A), 255.0f, fabsf(B)) * 4.76837158203125e-7f;
+                const bool neg = inv[k] < 0.0f;
+                tn = fmaxf(tn, fmaf((float)(neg ? qhi[k][sl] : qlo[k][sl]), A, B - E));
+                tf = fminf(tf, fmaf((float)(neg ? qlo[k][sl] : qhi[k][sl]), A, B + E));
+            }
+            if (!(tn <= tf)) continue;
+            if (is_inner) inner[n_inner++] = {(uint32_t)sl ^ oinv, n.child_base + my_rel};
+            else {
+                const uint32_t cnt_bits = meta >> 5, off = meta & 31u;
+                for (uint32_t k = 0; k < 3; ++k)
+                    if ((cnt_bits >> k) & 1u) { tris++; float t; if (ray_tri(a.woop[n.tri_base + off + k], o, d, tmax, t)) return true; }
+            }
+        }
+        for (int i = 0; i < n_inner; ++i) for (int j = i + 1; j < n_inner; ++j) if (inner[j].key < inner[i].key) std::swap(inner[i], inner[j]);
+        for (int i = 0; i < n_inner; ++i) stack.push_back(inner[i].node);
+    }
+    return false;
+}
+// any-hit of a packet: a ray that has found its occluder stops taking part
+void walk_packet_any(const Accel &a, const std::vector<std::array<float,3>> &O, const std::vector<std::array<float,3>> &D, const std::vector<float> &tmax, uint64_t &pn, uint64_t &pt) {
+    const size_t R = O.size();
+    std::vector<char> done(R, 0);
+    std::vector<std::array<float,3>> inv(R);
+    for (size_t r = 0; r < R; ++r) for (int k = 0; k < 3; ++k) inv[r][k] = safe_inv(D[r][k]);
+    const uint32_t oinv = 7u - ((inv[0][0] < 0 ? 1u : 0u) | (inv[0][1] < 0 ? 2u : 0u) | (inv[0][2] < 0 ? 4u : 0u));
+    std::vector<uint32_t> stack{0};
+    size_t left = R;
+    while (!stack.empty() && left) {
+        const uint32_t ni = stack.back(); stack.pop_back();
+        const Node8 &n = a.nodes[ni];
+        pn++;
+        const uint8_t ebytes[3] = {n.ex, n.ey, n.ez};
+        const float p[3] = {n.px, n.py, n.pz};
+        const uint8_t *qlo[3] = {n.qlox, n.qloy, n.qloz}, *qhi[3] = {n.qhix, n.qhiy, n.qhiz};
+        struct Child { uint32_t key, node; };
+        Child inner[8]; int n_inner = 0; uint32_t rel = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            const uint8_t meta = n.meta[sl];
+            const bool is_inner = (n.imask >> sl) & 1u;
+            const uint32_t my_rel = rel;
+            if (is_inner) rel++;
+            if (!meta) continue;
+            bool any = false;
+            for (size_t r = 0; r < R && !any; ++r) {
+                if (done[r]) continue;
+                float tn = 0.0f, tf = tmax[r];
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t bits = (uint32_t)ebytes[k] << 23; float scale; memcpy(&scale, &bits, 4);
+                    const float A = scale * inv[r][k], B = (p[k] - O[r][k]) * inv[r][k];
+                    const float E = fmaf(fabsf(A), 255.0f, fabsf(B)) * 4.76837158203125e-7f;
+                    const bool neg = inv[r][k] < 0.0f;
+                    tn = fmaxf(tn, fmaf((float)(neg ? qhi[k][sl] : qlo[k][sl]), A, B - E));
+                    tf = fminf(tf, fmaf((float)(neg ? qlo[k][sl] : qhi[k][sl]), A, B + E));
+                }
+                any = tn <= tf;
+            }
+            if (!any) continue;
+            if (is_inner) inner[n_inner++] = {(uint32_t)sl ^ oinv, n.child_base + my_rel};
+            else {
+                const uint32_t cnt_bits = meta >> 5, off = meta & 31u;
+                for (uint32_t k = 0; k < 3; ++k)
+                    if ((cnt_bits >> k) & 1u) { pt++; for (size_t r = 0; r < R; ++r) { float t; if (!done[r] && ray_tri(a.woop[n.tri_base + off + k], O[r].data(), D[r].data(), tmax[r], t)) { done[r] = 1; left--; } } }
+            }
+        }
+        for (int i = 0; i < n_inner; ++i) for (int j = i + 1; j < n_inner; ++j) if (inner[j].key < inner[i].key) std::swap(inner[i], inner[j]);
+        for (int i = 0; i < n_inner; ++i) stack.push_back(inner[i].node);
+    }
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -192,6 +286,7 @@ int main(int argc, char **argv) {
     for (int shape = 0; shape < 3; ++shape) {
         const int bw = shape == 0 ? 8 : shape == 1 ? 32 : 16, bh = 64 / bw;
         uint64_t in = 0, it = 0, pn = 0, pt = 0, packets = 0, mism = 0;
+        uint64_t sh_pn = 0, sh_pt = 0, sh_packets = 0, sh_in = 0, sh_it = 0, sh_rays = 0;
         for (int k = 0; k < 3000; ++k) {
             const int bx = (int)(rng() % (W / bw)) * bw, by = (int)(rng() % (H / bh)) * bh;
             std::vector<std::array<float,3>> O, D;
@@ -202,12 +297,31 @@ int main(int argc, char **argv) {
                 O.push_back({eye[0], eye[1], eye[2]}); D.push_back({d[0]/l, d[1]/l, d[2]/l});
             }
             std::vector<Hit> hp; walk_packet(acc, O, D, pn, pt, hp);
+            if (shape == 0) {   // the shadow rays of this packet's hits towards the atrium's 10 x 3 m ceiling light
+                std::vector<std::array<float,3>> SO, SD; std::vector<float> ST;
+                std::uniform_real_distribution<float> U(-1.f, 1.f);
+                for (size_t r = 0; r < O.size(); ++r) {
+                    if (hp[r].prim == 0xFFFFFFFFu) continue;
+                    float P[3], L[3] = {0.f + 5.f * U(rng), 10.9f, 0.f + 1.5f * U(rng)}, dd[3];
+                    for (int c = 0; c < 3; ++c) P[c] = O[r][c] + hp[r].t * D[r][c];
+                    float len = 0; for (int c = 0; c < 3; ++c) { dd[c] = L[c] - P[c]; len += dd[c] * dd[c]; }
+                    len = sqrtf(len); if (!(len > 1e-3f)) continue;
+                    for (int c = 0; c < 3; ++c) dd[c] /= len;
+                    SO.push_back({P[0] + 1e-3f * dd[0], P[1] + 1e-3f * dd[1], P[2] + 1e-3f * dd[2]}); SD.push_back({dd[0], dd[1], dd[2]}); ST.push_back(len - 2e-3f);
+                }
+                if (!SO.empty()) {
+                    walk_packet_any(acc, SO, SD, ST, sh_pn, sh_pt); sh_packets++;
+                    for (size_t r = 0; r < SO.size(); ++r) { walk_any(acc, SO[r].data(), SD[r].data(), ST[r], sh_in, sh_it); sh_rays++; }
+                }
+            }
             for (size_t r = 0; r < O.size(); ++r) { Stats st; Hit h = walk(acc, O[r].data(), D[r].data(), st); in += st.nodes; it += st.tris; if (h.prim != hp[r].prim || h.t != hp[r].t) mism++; }
             packets++;
         }
         const double Ni = (double)in / (packets * 64), Ti = (double)it / (packets * 64), Np = (double)pn / packets, Tp = (double)pt / packets;
         printf("packet %2dx%-2d: individual nodes/ray %.2f tris/ray %.2f | packet nodes %.1f tris %.1f | mismatches %llu | VALU model: packet %.0f vs individual %.0f wave-instr per 64 rays\n",
                bw, bh, Ni, Ti, Np, Tp, (unsigned long long)mism, Np * 245 + Tp * 60, 64.0 * Ni / 44.0 * 330.0);
+        if (sh_packets) printf("  shadow rays of those hits: individual nodes/ray %.2f tris/ray %.2f (%.1f rays per packet) | packet nodes %.1f tris %.1f\n",
+                               (double)sh_in / sh_rays, (double)sh_it / sh_rays, (double)sh_rays / sh_packets, (double)sh_pn / sh_packets, (double)sh_pt / sh_packets);
     }
     return 0;
 }
