@@ -1466,6 +1466,16 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         HIP_TRY(hipStreamSynchronize(s));
         int st = alloc_ray_buffers(wf, n_rays);
         if (st != LPT_OK) return st;
+        // the next wavefronts of this size take the other lanes: give them their buffers now, not in the middle of a later frame
+        // (a first-use hipMalloc of gigabytes takes tens of milliseconds on some hosts)
+        for (int l = 0; split && !denoise && l < r->n_lanes; ++l) {
+            if (l == lane || r->wf[l].ray_cap >= (size_t)n_rays) continue;
+            st = ensure_lane(r, l);
+            if (st != LPT_OK) return st;
+            HIP_TRY(hipStreamSynchronize(r->wf[l].stream));
+            st = alloc_ray_buffers(r->wf[l], n_rays);
+            if (st != LPT_OK) return st;
+        }
     }
     GBufArgs gb{};
     if (denoise) {

@@ -126,7 +126,7 @@ __device__ __forceinline__ void st_nt(float4 *p, const float4 v) { const f4v w =
 
 // pixel slot -> pixel.  Slots enumerate this rank's tiles in ascending tile id (period after period of V tiles, the rank's
 // virtual ranks inside a period; with unit weights: tile ids rank, rank+world, ...) and the pixels inside each tile row-major,
-// so a wave64 covers a 32x2 pixel block.
+// (in 8x8 blocks when the tile sides allow, within_to_xy below), so a wave64 covers an 8x8 pixel block.
 __device__ __forceinline__ void within_to_xy(const FrameParams &p, uint32_t within, uint32_t &wx, uint32_t &wy) {
     if (p.block8) {
         const uint32_t block = within >> 6, in = within & 63u, per_row = p.tile_w >> 3;
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameParams p, const floa
 }
 
 // ------------------------------------------------------------------ frame exchange (owned-tile gather)
-// A rank's owned pixels in SLOT order (tile after tile, row-major inside a tile): what travels to rank 0.  Slots of
+// A rank's owned pixels in SLOT order (tile after tile, inside a tile as slot_to_pixel orders them): what travels to rank 0.  Slots of
 // edge tiles that fall outside the image carry zeros and are never read back.
 __global__ __launch_bounds__(kBlock) void k_pack_owned(FrameParams p, const float4 *accum, float4 *out) {
     const uint32_t stride = gridDim.x * blockDim.x;

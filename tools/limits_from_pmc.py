@@ -113,7 +113,7 @@ def main(tag, out):
     h, m = per_launch(k2, "TCC_HIT_sum"), per_launch(k2, "TCC_MISS_sum")
     if h is not None and m is not None and h + m > 0:
         lim["k_shade_tcc_hit"] = h / (h + m)
-    # the whole frame against the VALU issue bound: a frame = 9 k_trace + 8 k_shade launches (depth 8), the other kernels are < 1 %
+    # the whole frame against the VALU issue bound: a frame = 8 k_trace + 8 k_shade launches + the packet launch of bounce 0 (depth 8), the other kernels are < 1 %
     vt, vs = per_launch(k, "SQ_INSTS_VALU"), per_launch(k2, "SQ_INSTS_VALU")
     gt = per_launch(k, "GRBM_GUI_ACTIVE")
     b2 = {}
@@ -130,11 +130,12 @@ def main(tag, out):
     if vt and vs and gt and avg_ns and b2.get("ms_per_frame"):
         clock = (gt / 8.0) / (avg_ns * 1e-9)                      # Hz the PMC pass actually ran at
         ceiling = 1.0 / (FAST_SHARE / FAST_RATE + (1 - FAST_SHARE) / SLOW_RATE)
-        insts = 9.0 * vt + 8.0 * vs
+        vp = per_launch("k_trace_packet<false>", "SQ_INSTS_VALU") or 0.0
+        insts = 8.0 * vt + 8.0 * vs + vp
         bound_ms = insts / SIMDS / ceiling / clock * 1e3
-        lim["frame_valu"] = {"valu_wave_insts_per_frame": insts, "k_trace_share": 9.0 * vt / insts, "bound_ms_per_frame": bound_ms,
+        lim["frame_valu"] = {"valu_wave_insts_per_frame": insts, "k_trace_share": 8.0 * vt / insts, "k_trace_packet_share": vp / insts, "bound_ms_per_frame": bound_ms,
                              "measured_ms_per_frame": b2["ms_per_frame"], "measured_from": b2.get("_source"), "frac": bound_ms / b2["ms_per_frame"], "clock_hz": clock,
-                             "note": "all VALU wave-instructions of a frame (9 k_trace + 8 k_shade launches) at the issue ceiling of k_trace's mix vs the "
+                             "note": "all VALU wave-instructions of a frame (8 k_trace + 8 k_shade launches + the packet launch of bounce 0) at the issue ceiling of k_trace's mix vs the "
                                      "measured frame (the SURVEY 8d span: one renderer, read-back included)"}
     wv, wc, bc = per_launch(k, "SQ_WAVES"), per_launch(k, "SQ_WAVE_CYCLES"), per_launch(k, "SQ_BUSY_CYCLES")
     if wv:
