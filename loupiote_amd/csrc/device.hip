@@ -1555,7 +1555,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
                 stage_begin(r, ST_PRIMARY, s);
                 const uint32_t packets = div_up(n_rays, 64u);
-                const size_t plds = (size_t)(7u * r->sg->stats.max_depth + 8u) * sizeof(uint32_t);
+                const size_t plds = (size_t)(48u + 7u * r->sg->stats.max_depth + 8u) * sizeof(uint32_t);   // 48 planes + the stack
                 if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
                 else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
                 stage_end(r, s);

@@ -780,7 +780,10 @@ __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, f
 // The wave's stack (node indices) is one LDS column per wave.  Works for any rays; it only pays for coherent ones.
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
-    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // 7 siblings per level + the path: (7 * depth + 8) entries (host)
+    // LDS of the wave: the 48 child planes of the node in hand as floats (192 B), then the stack of node indices — 7 siblings per
+    // level + the path: (7 * depth + 8) entries (host)
+    float *planes = reinterpret_cast<float *>(lds_dyn);
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn) + 48;
     // read-only for the whole launch and never aliased by what the kernel writes: lets the uniform fetches below become scalar loads
     const DNode8 *__restrict__ nodes = sc.nodes;
     const float4 *__restrict__ woop = sc.woop;
@@ -797,6 +800,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
         const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
         Hit best;
         best.t = live ? LPT_T_INF : 0.0f; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;   // a dead lane's interval [0, 0] meets nothing
+        // where this lane finds its near / far planes among the node's 48 (qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]): fixed per ray
+        const uint32_t onx = negx ? 24u : 0u, ofx = negx ? 0u : 24u, ony = negy ? 32u : 8u, ofy = negy ? 8u : 32u, onz = negz ? 40u : 16u, ofz = negz ? 16u : 40u;
         // visit order: the first lane's octant stands for the packet
         const uint32_t oinv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(7u - ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u))));
         int sp = 0;
@@ -805,6 +810,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
         while (have) {
             uint4 n0, n1, n2, n3, n4;
             sload_node(nodes + node_index, n0, n1, n2, n3, n4);   // wave-uniform address
+            // the 48 quantised planes are the same for every lane: lane j converts plane j — ONE conversion instruction for the wave
+            // instead of 48 — and LDS hands each lane the ones it needs (its near and far plane per axis, four children per read)
+            if (lane < 48u) planes[lane] = (float)reinterpret_cast<const uint8_t *>(nodes + node_index)[32u + lane];
+            __syncthreads();
             if (STATS) visits++;
             const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
             const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
@@ -820,19 +829,19 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
             const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
             const float tbest = best.t;
             uint32_t entered = 0u;   // wave-uniform: slots some lane's ray enters
-#pragma unroll
+#pragma nounroll   // 24 plane values live at a time, not 48: 7 waves per SIMD instead of 5
             for (int half = 0; half < 2; ++half) {
-                const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
-                const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
+                const float4 pnx = *reinterpret_cast<const float4 *>(planes + onx + 4 * half), pfx = *reinterpret_cast<const float4 *>(planes + ofx + 4 * half);
+                const float4 pny = *reinterpret_cast<const float4 *>(planes + ony + 4 * half), pfy = *reinterpret_cast<const float4 *>(planes + ofy + 4 * half);
+                const float4 pnz = *reinterpret_cast<const float4 *>(planes + onz + 4 * half), pfz = *reinterpret_cast<const float4 *>(planes + ofz + 4 * half);
+                const float qnx[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, qfx[4] = {pfx.x, pfx.y, pfx.z, pfx.w};
+                const float qny[4] = {pny.x, pny.y, pny.z, pny.w}, qfy[4] = {pfy.x, pfy.y, pfy.z, pfy.w};
+                const float qnz[4] = {pnz.x, pnz.y, pnz.z, pnz.w}, qfz[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int sh = 8 * j;
-                    const float qlx = (float)((lox >> sh) & 0xFFu), qhx = (float)((hix >> sh) & 0xFFu);   // uniform conversions
-                    const float qly = (float)((loy >> sh) & 0xFFu), qhy = (float)((hiy >> sh) & 0xFFu);
-                    const float qlz = (float)((loz >> sh) & 0xFFu), qhz = (float)((hiz >> sh) & 0xFFu);
-                    const float tnx = fmaf(negx ? qhx : qlx, ax, bnx), tfx = fmaf(negx ? qlx : qhx, ax, bfx);
-                    const float tny = fmaf(negy ? qhy : qly, ay, bny), tfy = fmaf(negy ? qly : qhy, ay, bfy);
-                    const float tnz = fmaf(negz ? qhz : qlz, az, bnz), tfz = fmaf(negz ? qlz : qhz, az, bfz);
+                    const float tnx = fmaf(qnx[j], ax, bnx), tfx = fmaf(qfx[j], ax, bfx);
+                    const float tny = fmaf(qny[j], ay, bny), tfy = fmaf(qfy[j], ay, bfy);
+                    const float tnz = fmaf(qnz[j], az, bnz), tfz = fmaf(qfz[j], az, bfz);
                     const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                     const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
                     if (__ballot(tn <= tf) != 0ull) entered |= 1u << (4 * half + j);
