@@ -283,15 +283,20 @@ int main(int argc, char **argv) {
     float up[3] = {right[1]*fwd[2]-right[2]*fwd[1], right[2]*fwd[0]-right[0]*fwd[2], right[0]*fwd[1]-right[1]*fwd[0]};
     const float eye[3] = {-10.0f, 1.0f, 0.0f};
     std::mt19937 rng(3);
-    for (int shape = 0; shape < 3; ++shape) {
-        const int bw = shape == 0 ? 8 : shape == 1 ? 32 : 16, bh = 64 / bw;
+    for (int shape = 0; shape < 5; ++shape) {
+        // shapes 3, 4: jittered rays (as the integrator's are) — 8x8 pixels x 1 sample, 4x4 pixels x 4 samples
+        const int spp = shape == 4 ? 4 : 1;
+        const bool jitter = shape >= 3;
+        const int bw = shape == 0 || shape == 3 ? 8 : shape == 1 ? 32 : shape == 2 ? 16 : 4, bh = 64 / spp / bw;
+        std::uniform_real_distribution<float> J(0.f, 1.f);
         uint64_t in = 0, it = 0, pn = 0, pt = 0, packets = 0, mism = 0;
         uint64_t sh_pn = 0, sh_pt = 0, sh_packets = 0, sh_in = 0, sh_it = 0, sh_rays = 0;
         for (int k = 0; k < 3000; ++k) {
             const int bx = (int)(rng() % (W / bw)) * bw, by = (int)(rng() % (H / bh)) * bh;
             std::vector<std::array<float,3>> O, D;
-            for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x) {
-                const float sx = (bx + x + 0.5f) / W, sy = (by + y + 0.5f) / H, cx = (2*sx-1)*ax, cy = (1-2*sy)*ay;
+            for (int sm = 0; sm < spp; ++sm) for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x) {
+                const float jx = jitter ? J(rng) : 0.5f, jy = jitter ? J(rng) : 0.5f;
+                const float sx = (bx + x + jx) / W, sy = (by + y + jy) / H, cx = (2*sx-1)*ax, cy = (1-2*sy)*ay;
                 float d[3]; for (int c = 0; c < 3; ++c) d[c] = right[c]*cx + up[c]*cy + fwd[c];
                 const float l = sqrtf(d[0]*d[0]+d[1]*d[1]+d[2]*d[2]);
                 O.push_back({eye[0], eye[1], eye[2]}); D.push_back({d[0]/l, d[1]/l, d[2]/l});
@@ -318,8 +323,8 @@ int main(int argc, char **argv) {
             packets++;
         }
         const double Ni = (double)in / (packets * 64), Ti = (double)it / (packets * 64), Np = (double)pn / packets, Tp = (double)pt / packets;
-        printf("packet %2dx%-2d: individual nodes/ray %.2f tris/ray %.2f | packet nodes %.1f tris %.1f | mismatches %llu | VALU model: packet %.0f vs individual %.0f wave-instr per 64 rays\n",
-               bw, bh, Ni, Ti, Np, Tp, (unsigned long long)mism, Np * 245 + Tp * 60, 64.0 * Ni / 44.0 * 330.0);
+        printf("packet %2dx%-2d%s: individual nodes/ray %.2f tris/ray %.2f | packet nodes %.1f tris %.1f | mismatches %llu | VALU model: packet %.0f vs individual %.0f wave-instr per 64 rays\n",
+               bw, bh, shape == 4 ? " x 4 spp (jittered)" : shape == 3 ? " (jittered)" : "", Ni, Ti, Np, Tp, (unsigned long long)mism, Np * 245 + Tp * 60, 64.0 * Ni / 44.0 * 330.0);
         if (sh_packets) printf("  shadow rays of those hits: individual nodes/ray %.2f tris/ray %.2f (%.1f rays per packet) | packet nodes %.1f tris %.1f\n",
                                (double)sh_in / sh_rays, (double)sh_it / sh_rays, (double)sh_rays / sh_packets, (double)sh_pn / sh_packets, (double)sh_pt / sh_packets);
     }
