@@ -46,10 +46,11 @@ struct DScene {
     const uint8_t *texels;       // RGBA8, all images back to back
     const DImage *images;
     const float *srgb_lut;       // 256 entries
-    // paired textures: (albedo RGBA8, mra RGBA8) per texel, 4x4-texel tiles of 128 B, for materials whose two textures have one
-    // size; such a material's record carries kPairedBit | pair index as its albedo texture (device.hip: device_material)
+    // paired textures: (albedo RGBA8, mra RGBA8) per texel in APRON tiles — 4x4 stored texels of 128 B that cover a 3x3 block of the image plus
+    // its right / lower neighbours (wrapped), so the four taps of a lookup never leave one cache line — for materials whose two textures
+    // have one size; such a material's record carries kPairedBit | pair index as its albedo texture (device.hip: device_material)
     const uint2 *pair_texels;
-    const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row
+    const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row (ceil(width / 3))
     uint32_t n_tris, n_materials, n_lights, n_images, n_pairs;
 };
 constexpr uint32_t kPairedBit = 0x40000000u;
@@ -963,9 +964,13 @@ __device__ __forceinline__ void texture_lookup_pair(const DScene &sc, const floa
     int y0 = wrap_i((int)y0f, H), y1 = wrap_next(y0, H);
     const uint2 *base = sc.pair_texels + im.offset;
     const uint32_t tiles_x = im.pad;
-    const uint32_t r0 = ((uint32_t)y0 >> 2) * tiles_x * 16u + ((uint32_t)y0 & 3u) * 4u, r1 = ((uint32_t)y1 >> 2) * tiles_x * 16u + ((uint32_t)y1 & 3u) * 4u;
-    const uint32_t c0 = ((uint32_t)x0 >> 2) * 16u + ((uint32_t)x0 & 3u), c1 = ((uint32_t)x1 >> 2) * 16u + ((uint32_t)x1 & 3u);
-    const uint2 p00 = base[r0 + c0], p10 = base[r0 + c1], p01 = base[r1 + c0], p11 = base[r1 + c1];
+    // apron tiles: the stored 4x4-texel tile (tx, ty) holds texels 3tx .. 3tx+3 x 3ty .. 3ty+3 (wrapped), so the 2x2 footprint of ANY lookup
+    // lies in the ONE 128-byte tile of its upper-left texel; x1 / y1 are the tile's next column / row by construction of the apron
+    (void)x1; (void)y1;
+    const uint32_t txi = ((uint32_t)x0 * 43691u) >> 17, tyi = ((uint32_t)y0 * 43691u) >> 17;   // / 3, exact below 98304
+    const uint32_t ix = (uint32_t)x0 - 3u * txi, iy = (uint32_t)y0 - 3u * tyi;
+    const uint2 *tile = base + ((size_t)tyi * tiles_x + txi) * 16u + iy * 4u + ix;
+    const uint2 p00 = tile[0], p10 = tile[1], p01 = tile[4], p11 = tile[5];
     float a[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
