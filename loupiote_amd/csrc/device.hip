@@ -120,6 +120,7 @@ struct lpt_scene_gpu {
     // textures have one size; the shading records of such materials carry kPairedBit | pair index instead of two image ids
     void *pair_texels = nullptr, *pair_images = nullptr;
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> pair_map;
+    std::vector<DImage> pair_descs;   // host copy: a paired material's record carries its pair's offset and size directly
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
     void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
@@ -411,7 +412,11 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
 static lpt_material device_material(const lpt_scene_gpu *sg, const lpt_material &m) {
     lpt_material d = m;
     const auto it = sg->pair_map.find(std::make_pair(m.albedo_texture, m.mra_texture));
-    if (it != sg->pair_map.end()) { d.albedo_texture = kPairedBit | it->second; d.mra_texture = LPT_INVALID_INDEX; }
+    if (it != sg->pair_map.end()) {
+        const DImage &di = sg->pair_descs[it->second];
+        d.albedo_texture = kPairedBit | di.offset;          // in 8-byte texels, < 2^30
+        d.mra_texture = di.width | (di.height << 16);       // both <= 65535 (checked when the pair is built)
+    }
     return d;
 }
 
@@ -558,7 +563,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
             const uint32_t a = m.albedo_texture, r = m.mra_texture;
             if (a >= scene->images.size() || r >= scene->images.size()) continue;
             const Image &ia = scene->images[a], &ir = scene->images[r];
-            if (ia.width != ir.width || ia.height != ir.height || !ia.width || !ia.height) continue;
+            if (ia.width != ir.width || ia.height != ir.height || !ia.width || !ia.height || ia.width > 65535u || ia.height > 65535u) continue;
             if (sg->pair_map.count(std::make_pair(a, r))) continue;
             // apron tiles (kernels.h texture_lookup_pair): a stored 4x4 tile covers a 3x3 block of the image + its right / lower neighbours
             const uint32_t tx = (ia.width + 2u) / 3u, ty = (ia.height + 2u) / 3u;
@@ -580,6 +585,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
                         }
             sg->pair_map[std::make_pair(a, r)] = (uint32_t)pair_descs.size();
             pair_descs.push_back(di);
+            sg->pair_descs.push_back(di);
         }
     }
     if (!gpu_build) {

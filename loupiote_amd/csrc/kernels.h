@@ -48,7 +48,8 @@ struct DScene {
     const float *srgb_lut;       // 256 entries
     // paired textures: (albedo RGBA8, mra RGBA8) per texel in APRON tiles — 4x4 stored texels of 128 B that cover a 3x3 block of the image plus
     // its right / lower neighbours (wrapped), so the four taps of a lookup never leave one cache line — for materials whose two textures
-    // have one size; such a material's record carries kPairedBit | pair index as its albedo texture (device.hip: device_material)
+    // have one size; such a material's record carries kPairedBit | the pair's texel offset as its albedo texture and width | height << 16 as its
+    // mra texture (device.hip: device_material)
     const uint2 *pair_texels;
     const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row (ceil(width / 3))
     uint32_t n_tris, n_materials, n_lights, n_images, n_pairs;
@@ -954,16 +955,17 @@ __device__ __forceinline__ float4 texture_lookup(const DScene &sc, const float *
 // Both textures of a material from ONE set of four taps (paired texels: x = albedo RGBA8, y = mra RGBA8).  The coordinates, the
 // weights and every product are those of two texture_lookup calls on images of this size, so the result is theirs bit for bit;
 // only albedo.rgb (sRGB-decoded) and mra.g / mra.b are produced, which is all the shading reads.
-__device__ __forceinline__ void texture_lookup_pair(const DScene &sc, const float *lut, uint32_t pair, float u, float v, f3 &albedo, float &mra_g, float &mra_b) {
-    const DImage im = sc.pair_images[pair];
-    const int W = (int)im.width, H = (int)im.height;
+__device__ __forceinline__ void texture_lookup_pair(const DScene &sc, const float *lut, uint32_t offset, uint32_t wh, float u, float v, f3 &albedo, float &mra_g, float &mra_b) {
+    // the pair's descriptor rides in the shading record itself (offset in 8-byte texels, width | height << 16): no table fetch between
+    // the record and the texels
+    const int W = (int)(wh & 0xFFFFu), H = (int)(wh >> 16);
     float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
     float x0f = floorf(fx), y0f = floorf(fy);
     float tx = fx - x0f, ty = fy - y0f;
     int x0 = wrap_i((int)x0f, W), x1 = wrap_next(x0, W);
     int y0 = wrap_i((int)y0f, H), y1 = wrap_next(y0, H);
-    const uint2 *base = sc.pair_texels + im.offset;
-    const uint32_t tiles_x = im.pad;
+    const uint2 *base = sc.pair_texels + offset;
+    const uint32_t tiles_x = (((uint32_t)W + 2u) * 43691u) >> 17;   // ceil(W / 3)
     // apron tiles: the stored 4x4-texel tile (tx, ty) holds texels 3tx .. 3tx+3 x 3ty .. 3ty+3 (wrapped), so the 2x2 footprint of ANY lookup
     // lies in the ONE 128-byte tile of its upper-left texel; x1 / y1 are the tile's next column / row by construction of the apron
     (void)x1; (void)y1;
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                     if ((atex >> 30) == 1u) {   // kPairedBit set, not LPT_INVALID_INDEX: both textures of the material from one set of taps
                         f3 alb;
                         float mg, mb;
-                        texture_lookup_pair(sc, s_lut, atex & ~kPairedBit, tu, tvv, alb, mg, mb);
+                        texture_lookup_pair(sc, s_lut, atex & ~kPairedBit, mtex, tu, tvv, alb, mg, mb);
                         base.x *= alb.x; base.y *= alb.y; base.z *= alb.z;
                         rough *= mg; metal *= mb;
                     } else {
