@@ -27,8 +27,10 @@ Besides `value` the line carries
   throughput  --pipeline P renderers in flight (own HIP streams and, for N>1, own RCCL communicators), the 4 spp of a frame as
               raytrace_n(view, 4), no read-back: what the hardware sustains when frames overlap (round 2's `value`);
   latency_ms  one frame alone without the read-back;
-  roofline    k_trace: algorithmic bytes per launch / the launch time (HIP events on the stream the kernel runs on; one frame
-              at a time, nothing co-running) / 8 TB/s, with the PMC-derived limits of profiles/limits.json;
+  roofline    k_trace (the per-ray traversal of bounces 1.. and of every shadow ray): algorithmic bytes per launch / the launch
+              time (HIP events on the stream the kernel runs on; one frame at a time, nothing co-running) / 8 TB/s, with the
+              PMC-derived limits of profiles/limits.json; roofline.packet: the same for k_trace_packet, which traces bounce 0
+              as packets of 64 coherent rays (one tree walk per packet);
   rccl        (N>1) what RCCL itself reports for the communicator, the exchange time per frame (HIP events around
               lpt_renderer_exchange on rank 0), per-rank ray counts, and whether rank 0's presented frame was complete;
   cpu_baseline  the oracle ("port") on the host cores, bounded sample.
