@@ -77,6 +77,9 @@ def parse_args(argv=None):
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
     ap.add_argument("--root-weight", type=int, default=0, help="N>1: tile-ownership weight of rank 0 against 8 for every other rank (lpt_renderer_set_shard_weighted): "
                     "rank 0 also unpacks, resolves and reads back the frame, so it gets fewer tiles; 0 = calibrate in the warm-up, 8 = equal shares")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: path_rays, "
+                    "path_waves_per_cu, path_refill, pipe_rays, packet_primary, merge_trace, refill, trace_waves_per_cu, shade_blocks_per_cu, wavefront_rays); every value gives the same frame")
+    ap.add_argument("--no-shard-emulation", action="store_true", help="skip the shard_emulation leg (rank 0's 1/2, 1/4, 1/8 tile shard of the frame on this GPU)")
     ap.add_argument("--eager", action="store_true", help="experiments: every raytrace() launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour)")
     ap.add_argument("--max-fused", type=int, default=0, help="experiments: lpt_renderer_set_max_fused(n) on the timed renderer (0 = the library's default)")
     ap.add_argument("--lanes", type=int, default=0, help="experiments: wavefront lanes of the timed renderer (0 = the library's default)")
@@ -296,6 +299,10 @@ def run(args):
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29517"
         dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only (id rendezvous, barriers, max over ranks)
 
+    from loupiote_amd import api as lp_api
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        lp_api.DEFAULT_OPTIONS[k] = int(v)
     dev = lp.Device(local_rank)
     P = args.pipeline if args.pipeline > 0 else (4 if (world > 1 or args.emulate_shard > 1) else 3)
     extras = not args.no_extras
@@ -321,7 +328,8 @@ def run(args):
 
     weights = [None]   # tile-ownership weights of the ranks (None = equal shares), the same on every rank
 
-    def make_renderer(comm=None, lanes=None):
+    def make_renderer(comm=None, lanes=None, shard=None):
+        shard = shard or args.emulate_shard
         rr = lp.Renderer(dev, (WIDTH, HEIGHT))
         if lanes:
             rr.set_lanes(lanes)
@@ -334,8 +342,8 @@ def run(args):
         if comm is not None:
             rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)
-        elif args.emulate_shard > 1:
-            rr.set_shard(0, args.emulate_shard, 32, 8)
+        elif shard > 1:
+            rr.set_shard(0, shard, 32, 8)
             rr.set_resources(dev, sg, probe)
         return rr
 
@@ -386,7 +394,7 @@ def run(args):
             t_frame = (time.perf_counter() - tc) / CAL * 1e3
             tm = r.timings()
             r.enable_timings(False)
-            t_tr = sum(tm.get(k, (0.0, 0))[0] for k in ("ray generation", "intersection", "shading", "shadow", "accumulation")) / CAL
+            t_tr = sum(tm.get(k, (0.0, 0))[0] for k in ("ray generation", "primary intersection", "intersection", "shading", "shadow", "path", "accumulation")) / CAL
             tt_ = torch.tensor([t_tr], dtype=torch.float64)
             dist.all_reduce(tt_, op=dist.ReduceOp.SUM)
             t_tr_mean = float(tt_.item()) / world
@@ -555,6 +563,40 @@ def run(args):
             readback["exposed_in_span_ms"] = elapsed / n_frames * 1e3 - latency["median"]
     r.close()
 
+    # ================================================================== strong scaling of ONE frame, emulated: rank 0's 1/N tile shard on this GPU
+    # What the tracing of a frame costs a rank of an N-GPU job (interleaved 32x8 tiles, replicated scene), in the span form —
+    # reset; 4 x raytrace; read_radiance of the whole frame buffer, one frame at a time — measured here because the driver has no
+    # multi-GPU node to run `--gpus N` on.  No exchange is in it: an upper bound of the speed-up N GPUs can give one frame.
+    shard_emulation = None
+    if extras and world == 1 and not args.emulate_shard and not args.no_shard_emulation:
+        shard_emulation = {"what": "ms per frame of rank 0's 1/N tile shard (32x8 tiles, tile id mod N) rendered alone on this GPU in the span form (reset_accumulation; %d x raytrace; "
+                                   "read_radiance of the frame buffer), median of 12 frames after 4 warm-up frames; no exchange; '1' = the whole frame, the same way" % SPP}
+        for n_sh in (1, 2, 4, 8):
+            rr = make_renderer(lanes=args.lanes or None, shard=n_sh)
+            ts = []
+            for k in range(16):
+                rr.synchronize()
+                t1 = time.perf_counter()
+                rr.reset_accumulation()
+                rr.accumulate = True
+                for _ in range(SPP):
+                    rr.raytrace(view)
+                rr.read_radiance(out=dst)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            ts = sorted(ts[4:])
+            cc = rr.ray_counts()
+            rr.enable_timings(True)
+            rr.reset_accumulation()
+            rr.accumulate = True
+            for _ in range(SPP):
+                rr.raytrace(view)
+            rr.synchronize()
+            stg = {k: v[0] for k, v in rr.timings().items() if v[1]}
+            rr.close()
+            shard_emulation[str(n_sh)] = {"ms_per_frame": ts[len(ts) // 2], "min_ms": ts[0], "rays_per_frame": (cc.closest + cc.shadow) / 16.0, "stage_ms": stg}
+        for n_sh in (2, 4, 8):
+            shard_emulation[str(n_sh)]["speedup_vs_1"] = shard_emulation["1"]["ms_per_frame"] / shard_emulation[str(n_sh)]["ms_per_frame"]
+
     # ================================================================== throughput: P renderers in flight, batched samples, no read-back
     throughput = None
     if tp_leg:
@@ -655,6 +697,7 @@ def run(args):
             "throughput": throughput,
             "latency_ms": latency,
             "readback": readback,
+            "shard_emulation": shard_emulation,
             "rccl": rccl,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": s_achieved / HBM_PEAK_GBS,

@@ -172,6 +172,8 @@ class Renderer {  // renderer.rs:169-811
     void set_comm(const Comm *comm, const uint32_t *weights = nullptr) { check(lpt_renderer_set_comm_weighted(h_, comm ? comm->handle() : nullptr, weights)); }     // = set_shard(rank, world, 32, 8, weights) + the binding
     void exchange(int mode = LPT_EXCHANGE_GATHER_TILES) { check(lpt_renderer_exchange(h_, mode)); }             // rank 0 presents the whole frame
     void set_sort_queues(int flag) { check(lpt_renderer_set_sort_queues(h_, flag)); }
+    void set_option(lpt_option option, uint64_t value) { check(lpt_renderer_set_option(h_, (int)option, value)); }
+    uint64_t get_option(lpt_option option) const { uint64_t v = 0; check(lpt_renderer_get_option(h_, (int)option, &v)); return v; }
     lpt_ray_counts ray_counts() { lpt_ray_counts c; check(lpt_renderer_get_ray_counts(h_, &c)); return c; }
     /// multi-GPU denoising: this rank's filter inputs (device pointers) and, on rank 0 after the exchange, the filter passes
     void denoiser_inputs(void **noisy, void **gbuffer, void **motion, size_t *n_pixels) { check(lpt_renderer_denoiser_inputs(h_, noisy, gbuffer, motion, n_pixels)); }

@@ -146,7 +146,7 @@ typedef struct lpt_ray_counts {
 } lpt_ray_counts;
 
 typedef struct lpt_timing {
-    char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection" */
+    char label[32]; /* "ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection", "path" */
     float ms;       /* summed over every raytrace() since enable_timings(1) */
     uint32_t launches;
 } lpt_timing;
@@ -496,6 +496,26 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes);
  * not change by a bit; only traversal coherence does.  flag: 1 = next-bounce queue only, 2 = shadow queue only, 3 (or any
  * other non-zero value) = both.  Default: off (measured slower on the bench scene). */
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
+/* new (no reference knob; SURVEY §5 "Config / flags: no"): launch tuning for experiments and for the tests that compare the kernel
+ * variants.  EVERY value gives the same frame bit for bit — only which kernels run, and the size of their grids, changes.  The
+ * library reads no environment variable for any of this (round 3 did; a host's environment must not change which kernels run). */
+typedef enum lpt_option {
+    LPT_OPT_MERGE_TRACE = 1,        /* 1 (default): closest-hit rays of bounce b+1 and shadow rays of bounce b in one launch; 0: separate launches */
+    LPT_OPT_PACKET_PRIMARY = 2,     /* 1 (default): bounce 0 by packet traversal, one tree walk per 64 coherent rays; 0: per ray */
+    LPT_OPT_PIPE_RAYS = 3,          /* wavefronts of at most this many rays trace with the one-round-trip step (default: all); 0: never */
+    LPT_OPT_WAVEFRONT_RAYS = 4,     /* rays per wavefront an automatic submission aims at (default 4 194 304) */
+    LPT_OPT_REFILL = 5,             /* per-bounce traversal: lanes live below which a wave refills (default 44) */
+    LPT_OPT_TRACE_WAVES_PER_CU = 6, /* per-bounce traversal: persistent waves per CU; 0 (default): sized from the ray count */
+    LPT_OPT_SHADE_BLOCKS_PER_CU = 7,/* shading pass: blocks per CU (default 4) */
+    LPT_OPT_PATH_RAYS = 8,          /* wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (the
+                                     * path kernel: no chip-wide barrier per bounce — small frames and the tile shards of a wide multi-GPU
+                                     * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 800 000, the
+                                     * measured cross-over; 0: never */
+    LPT_OPT_PATH_WAVES_PER_CU = 9,  /* path kernel: persistent waves per CU (default 16) */
+    LPT_OPT_PATH_REFILL = 10        /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
+} lpt_option;
+int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
+int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);
 /* The shard layout lpt_renderer_set_shard / lpt_renderer_exchange use, for hosts that run their own exchange (pure host
  * arithmetic, no GPU needed): the number of pixel slots rank `rank` owns (whole tiles, including the part of edge tiles
  * outside the image) and where its slots start in the concatenation of all ranks' slot arrays on rank 0. */

@@ -19,6 +19,9 @@ LPT_ERR_HIP = 4
 LPT_ERR_RCCL = 5
 LPT_ERR_INVALID_ARG = 6
 COMM_ID_BYTES = 128
+# lpt_option (include/lpt.h): launch tuning behind lpt_renderer_set_option; every value gives the same frame
+OPTIONS = {"merge_trace": 1, "packet_primary": 2, "pipe_rays": 3, "wavefront_rays": 4, "refill": 5, "trace_waves_per_cu": 6,
+           "shade_blocks_per_cu": 7, "path_rays": 8, "path_waves_per_cu": 9, "path_refill": 10}
 EXCHANGE_GATHER_TILES = 0
 EXCHANGE_REDUCE = 1
 INVALID_INDEX = 0xFFFFFFFF
@@ -152,6 +155,8 @@ SIGNATURES = {
     "lpt_renderer_set_comm_weighted": (_i, [_vp, _vp, _vp]),
     "lpt_renderer_set_lanes": (_i, [_vp, _i]),
     "lpt_renderer_set_sort_queues": (_i, [_vp, _i]),
+    "lpt_renderer_set_option": (_i, [_vp, _i, C.c_uint64]),
+    "lpt_renderer_get_option": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "lpt_renderer_get_queue_counts": (_i, [_vp, _vp, _vp, _u32]),
     "lpt_renderer_get_ray_counts": (_i, [_vp, C.POINTER(RayCounts)]),
     "lpt_renderer_reset_ray_counts": (_i, [_vp]),

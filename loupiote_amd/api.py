@@ -285,6 +285,12 @@ class ProbeGPU:
             self._h = None
 
 
+# launch options (`Renderer.set_option`) every new Renderer of this process starts with: how the test suite runs one test body over
+# both forms of the frame pipeline (tests/conftest.py `pipeline`) and bench.py applies `--opt name=value`.  Host-side only: the
+# library itself reads no environment variable and has no process-wide state for this.
+DEFAULT_OPTIONS = {}
+
+
 class Renderer:
     """renderer.rs:169-811."""
 
@@ -294,6 +300,8 @@ class Renderer:
         self._h = h
         self._dev = device
         self._downsample = 0.5
+        for k, v in DEFAULT_OPTIONS.items():
+            self.set_option(k, v)
 
     @staticmethod
     def max_ssbo_element_in_bytes():
@@ -458,6 +466,16 @@ class Renderer:
         """the shading pass emits both ray queues ordered by direction octant inside each block (bit-identical results)"""
         _check(A.lib().lpt_renderer_set_sort_queues(self._h, int(flag)))
 
+    def set_option(self, name, value):
+        """launch tuning (`_abi.OPTIONS`: merge_trace, packet_primary, pipe_rays, wavefront_rays, refill, trace_waves_per_cu,
+        shade_blocks_per_cu, path_rays, path_waves_per_cu, path_refill); every value gives the same frame bit for bit"""
+        _check(A.lib().lpt_renderer_set_option(self._h, A.OPTIONS[name] if isinstance(name, str) else int(name), int(value)))
+
+    def get_option(self, name):
+        v = C.c_uint64()
+        _check(A.lib().lpt_renderer_get_option(self._h, A.OPTIONS[name] if isinstance(name, str) else int(name), C.byref(v)))
+        return v.value
+
     def queue_counts(self, n=64):
         """per-bounce (closest-hit, shadow) queue sizes of the last traced frame"""
         c, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
@@ -484,10 +502,10 @@ class Renderer:
         _check(A.lib().lpt_renderer_enable_timings(self._h, int(bool(flag))))
 
     def timings(self):
-        n = C.c_int(8)
-        arr = (A.Timing * 8)()
+        n = C.c_int(16)
+        arr = (A.Timing * 16)()
         _check(A.lib().lpt_renderer_get_timings(self._h, arr, C.byref(n)))
-        return {arr[i].label.decode(): (arr[i].ms, arr[i].launches) for i in range(min(n.value, 8))}
+        return {arr[i].label.decode(): (arr[i].ms, arr[i].launches) for i in range(min(n.value, 16))}
 
     def stream(self):
         s = C.c_void_p()

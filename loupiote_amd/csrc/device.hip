@@ -138,10 +138,11 @@ struct lpt_probe {
     void *rgbe = nullptr;
 };
 
-enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_EXCHANGE, ST_PRIMARY, ST_COUNT };
+enum { ST_RAYGEN = 0, ST_INTERSECT, ST_SHADE, ST_SHADOW, ST_ACCUM, ST_ASVGF, ST_EXCHANGE, ST_PRIMARY, ST_PATH, ST_COUNT };
 // "primary intersection": the IntersectorPass of bounce 0 when it runs as packet traversal (k_trace_packet), timed apart from the
 // per-ray traversal launches ("intersection") because it is another kernel
-static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection"};
+// "path": every bounce behind the primary hits in ONE launch (k_path), the form small wavefronts — the tile shard of a multi-GPU frame — take
+static const char *kStageLabel[ST_COUNT] = {"ray generation", "intersection", "shading", "shadow", "accumulation", "asvgf", "exchange", "primary intersection", "path"};
 
 // One independent wavefront context ("lane") of a renderer: everything a raytrace() call owns while its rays are in flight.
 // Consecutive raytrace() calls of ONE renderer take the lanes in turn (default 2), so the traversal / shading of call k+1
@@ -160,6 +161,7 @@ struct Wavefront {
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
+constexpr uint32_t kPathRays = 800000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
 struct lpt_renderer {
@@ -167,7 +169,7 @@ struct lpt_renderer {
     hipStream_t stream = nullptr;   // every renderer enqueues on its OWN stream, so two renderers pipeline
                                     // consecutive frames (and a frame's collective overlaps the next frame)
     Wavefront wf[kMaxLanes];
-    int n_lanes = 2;                // lpt_renderer_set_lanes / LPT_LANES
+    int n_lanes = 2;                // lpt_renderer_set_lanes
     uint32_t lane_rr = 0;
     int last_lane = 0;
     uint32_t req_w = 0, req_h = 0, w = 0, h = 0;
@@ -185,9 +187,14 @@ struct lpt_renderer {
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
     uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
                                // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
-    bool packet_primary = true;    // bounce 0 by packet traversal (k_trace_packet); LPT_PACKET=0: per-ray traversal like every other bounce
-    uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_PIPE_RAYS=0: none
-    uint64_t wavefront_rays = kWavefrontRays;   // LPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
+    bool packet_primary = true;    // bounce 0 by packet traversal (k_trace_packet); LPT_OPT_PACKET_PRIMARY 0: per-ray traversal like every other bounce
+    uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_OPT_PIPE_RAYS 0: none
+    uint64_t wavefront_rays = kWavefrontRays;   // LPT_OPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
+    // wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (k_path: no chip-wide barrier per
+    // bounce); larger ones take the per-bounce launches, whose drains are then a few per cent.  LPT_OPT_PATH_RAYS; 0: never
+    uint32_t path_rays = kPathRays;
+    uint32_t path_waves_per_cu = 16;   // k_path: 4 waves per SIMD (kernels.h LPT_PATH_ATTR)
+    int path_refill = 32;              // k_path: a batch of lanes is shaded (and idle lanes start new paths) when at most this many lanes are tracing
     uint64_t n_recorded = 0, n_wavefronts = 0;   // raytrace() calls recorded / wavefronts submitted so far (lpt_renderer_get_submission_stats)
     int mode = LPT_BLIT_PATHTRACE;
     // build-only knobs
@@ -199,12 +206,12 @@ struct lpt_renderer {
     ShardTable h_table{};            // rank 0: the whole rule (staging offsets of the ranks) ...
     ShardTable *d_table = nullptr;   // ... and its copy in device memory for the unpack kernels; refreshed by alloc_frame_buffers
     bool use_noise = false, stats = false, timings = false;
-    // traversal tuning (env LPT_REFILL / LPT_WAVES_PER_CU override, for experiments)
+    // traversal tuning (lpt_renderer_set_option, for experiments)
     int refill = 44;
-    int sort_queues = 0;       // k_shade emits both ray queues ordered by direction octant within a block (lpt_renderer_set_sort_queues / LPT_SORT)
+    int sort_queues = 0;       // k_shade emits both ray queues ordered by direction octant within a block (lpt_renderer_set_sort_queues)
     bool merge_trace = true;
-    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
-    uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_WAVES_PER_CU pins it
+    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_OPT_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
+    uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_OPT_TRACE_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
     float4 *accum = nullptr, *scratch = nullptr;
@@ -242,8 +249,8 @@ struct lpt_renderer {
     int ev_stage[kRing][kMaxEvents]{};
     int ev_count[kRing]{};
     uint64_t ring_pos = 0;
-    double stage_ms[8]{};
-    uint32_t stage_launches[8]{};
+    double stage_ms[ST_COUNT]{};
+    uint32_t stage_launches[ST_COUNT]{};
 };
 
 static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
@@ -1104,21 +1111,12 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
         hipError_t se = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { delete r; return fail(LPT_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se)); }
     }
-    if (const char *ev = getenv("LPT_SHADE_BLOCKS_PER_CU")) r->shade_blocks_per_cu = (uint32_t)std::max(1, std::min(64, atoi(ev)));
-    if (const char *ev = getenv("LPT_MERGE_TRACE")) r->merge_trace = atoi(ev) != 0;
-    if (const char *ev = getenv("LPT_SORT")) r->sort_queues = atoi(ev) & 3;
-    if (const char *ev = getenv("LPT_REFILL")) r->refill = std::max(0, std::min(63, atoi(ev)));
-    if (const char *ev = getenv("LPT_WAVES_PER_CU")) r->trace_waves_per_cu = (uint32_t)std::max(1, std::min(32, atoi(ev)));
-    if (const char *ev = getenv("LPT_PACKET")) r->packet_primary = atoi(ev) != 0;
-    if (const char *ev = getenv("LPT_PIPE_RAYS")) r->pipe_rays = (uint32_t)std::max(0ll, std::min(0x7FFFFFFFll, atoll(ev)));
-    if (const char *ev = getenv("LPT_WAVEFRONT_RAYS")) r->wavefront_rays = (uint64_t)std::max(64ll, atoll(ev));
     r->prev_cam.origin = mk3(0.f, 0.f, 0.f); r->prev_cam.right = mk3(1.f, 0.f, 0.f); r->prev_cam.up = mk3(0.f, 1.f, 0.f);
     r->prev_cam.fwd = mk3(0.f, 0.f, 1.f); r->prev_cam.ax = r->prev_cam.ay = 1.0f;   // Mat4::IDENTITY (renderer.rs:319)
     r->req_w = width; r->req_h = height;
     // get_downsampled_size (renderer.rs:18-22)
     r->w = (uint32_t)((float)width * r->downsample);
     r->h = (uint32_t)((float)height * r->downsample);
-    if (const char *ev = getenv("LPT_LANES")) r->n_lanes = std::max(1, std::min(kMaxLanes, atoi(ev)));
     hipError_t e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
@@ -1332,6 +1330,43 @@ int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
     r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;   // 1: next-bounce queue, 2: shadow queue, 3 (or any other non-zero): both
     return LPT_OK;
 }
+// Launch tuning that experiments and the variant tests switch (the reference has no counterpart: SURVEY §5 "Config / flags: no").
+// Every value gives the same frame bit for bit; only which kernels run, and how large their grids are, changes.
+int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: null");
+    FLUSH_OR_RETURN(r);
+    switch (option) {
+    case LPT_OPT_MERGE_TRACE: r->merge_trace = value != 0; break;
+    case LPT_OPT_PACKET_PRIMARY: r->packet_primary = value != 0; break;
+    case LPT_OPT_PIPE_RAYS: r->pipe_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_WAVEFRONT_RAYS: r->wavefront_rays = std::max<uint64_t>(value, 64u); break;
+    case LPT_OPT_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_REFILL: 0..63"); r->refill = (int)value; break;
+    case LPT_OPT_TRACE_WAVES_PER_CU: if (value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_TRACE_WAVES_PER_CU: 0 (auto) or 1..32"); r->trace_waves_per_cu = (uint32_t)value; break;
+    case LPT_OPT_SHADE_BLOCKS_PER_CU: if (value < 1u || value > 64u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_SHADE_BLOCKS_PER_CU: 1..64"); r->shade_blocks_per_cu = (uint32_t)value; break;
+    case LPT_OPT_PATH_RAYS: r->path_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_PATH_WAVES_PER_CU: if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
+    case LPT_OPT_PATH_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
+    default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
+    }
+    return LPT_OK;
+}
+int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) {
+    if (!r || !value) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: null");
+    switch (option) {
+    case LPT_OPT_MERGE_TRACE: *value = r->merge_trace; break;
+    case LPT_OPT_PACKET_PRIMARY: *value = r->packet_primary; break;
+    case LPT_OPT_PIPE_RAYS: *value = r->pipe_rays; break;
+    case LPT_OPT_WAVEFRONT_RAYS: *value = r->wavefront_rays; break;
+    case LPT_OPT_REFILL: *value = (uint64_t)r->refill; break;
+    case LPT_OPT_TRACE_WAVES_PER_CU: *value = r->trace_waves_per_cu; break;
+    case LPT_OPT_SHADE_BLOCKS_PER_CU: *value = r->shade_blocks_per_cu; break;
+    case LPT_OPT_PATH_RAYS: *value = r->path_rays; break;
+    case LPT_OPT_PATH_WAVES_PER_CU: *value = r->path_waves_per_cu; break;
+    case LPT_OPT_PATH_REFILL: *value = (uint64_t)r->path_refill; break;
+    default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
+    }
+    return LPT_OK;
+}
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_stats: null");
     FLUSH_OR_RETURN(r);
@@ -1356,7 +1391,7 @@ int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
     if (flag) {  // (re)start accumulating
         HIP_TRY(hipStreamSynchronize(r->stream));
         for (int k = 0; k < lpt_renderer::kRing; ++k) r->ev_count[k] = 0;
-        for (int i = 0; i < 8; ++i) { r->stage_ms[i] = 0.0; r->stage_launches[i] = 0; }
+        for (int i = 0; i < ST_COUNT; ++i) { r->stage_ms[i] = 0.0; r->stage_launches[i] = 0; }
     }
     r->timings = flag != 0;
     return LPT_OK;
@@ -1571,7 +1606,21 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 stage_end(r, s);
             } else trace(0, -1);
         }
-        for (uint32_t b = 0; b < nb; ++b) {
+        // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
+        // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
+        const bool path = packet && r->path_rays && n_rays <= r->path_rays;
+        if (path) {
+            stage_begin(r, ST_PATH, s);
+            const uint32_t pblocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), std::max(8u, (cus * r->path_waves_per_cu) & ~7u));
+            const size_t plds = lds + kPathLdsExtra;   // stacks + sRGB table + per-bounce counters
+            if (denoise) {
+                if (r->stats) hipLaunchKernelGGL((k_path<true, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+                else hipLaunchKernelGGL((k_path<true, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+            } else if (r->stats) hipLaunchKernelGGL((k_path<false, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+            else hipLaunchKernelGGL((k_path<false, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+            stage_end(r, s);
+        }
+        for (uint32_t b = 0; b < nb && !path; ++b) {
             seed += 1u;                          // :453, :487
             const Queue qin = wf.q[b & 1u], qout = wf.q[(b + 1u) & 1u];
             if (!r->merge_trace) {

@@ -1074,6 +1074,172 @@ __device__ __forceinline__ float pow128(float x) { x = x * x; x = x * x; x = x *
 struct GBufArgs { uint4 *gbuf; float2 *motion; CamBasis cur, prev; };
 
 // ------------------------------------------------------------------ shading (SPEC §12)
+// What shading ONE hit produces besides the radiance it adds: the next ray of the path and its next-event shadow ray,
+// in the queue layout (Queue / ShadowQueue).
+struct ShadeOut {
+    bool want_next, want_shadow, is_surface;
+    float4 no4, nd4, nT4;   // (origin, pdf) (direction, slot bits) (throughput, x | y << 13 | sample << 26)
+    float4 so4, sd4, sc4;   // (origin, tmax) (direction, slot bits) (contribution)
+};
+
+// One hit of bounce `bounce` shaded (PrimaryRayPass / ShadingPass): miss -> RGBE probe; emitter -> MIS-weighted emission;
+// surface -> shading record, textures, NEE shadow ray and BSDF sample.  Shared by k_shade (one thread per queued ray,
+// radiance deposited into Lsum) and k_path (a lane carries its path through every bounce, radiance kept in registers):
+// `load_o()` returns the ray's (origin, pdf) record — only emitter hits and the G-buffer need it —, `add_l(r, g, b)`
+// adds to the path's radiance.
+template <bool GBUF, typename LoadO, typename AddL>
+__device__ __forceinline__ void shade_hit(const DScene &sc, const DProbe &probe, const DNoise &nz, const FrameParams &p, const float *s_lut,
+                                          const uint32_t bounce, const bool last_bounce, const uint32_t seed_base, const float inv_nl, const GBufArgs &gb,
+                                          const float4 d4, const float4 T4, const float4 h4, LoadO load_o, AddL add_l, ShadeOut &out) {
+    out.want_next = false; out.want_shadow = false; out.is_surface = false;
+    const uint32_t pxy = __float_as_uint(T4.w);  // x | y << 13 | sample << 26 (k_raygen)
+    const f3 d = mk3(d4.x, d4.y, d4.z);
+    const f3 T = mk3(T4.x, T4.y, T4.z);
+    const uint32_t prim = __float_as_uint(h4.w);
+    // primary-hit record for the G-buffer (SPEC §15.1); defaults cover miss / emitter / degenerate
+    f3 g_n = neg(d), g_alb = mk3(1.0f, 1.0f, 1.0f);
+    f3 g_P = mk3(0.f, 0.f, 0.f);
+    if (GBUF && bounce == 0) {
+        const float4 o4 = load_o();
+        g_P = mk3(fmaf(d.x, h4.x, o4.x), fmaf(d.y, h4.x, o4.y), fmaf(d.z, h4.x, o4.z));
+    }
+    if (prim == 0xFFFFFFFFu) {
+        const f3 e = env_lookup(probe, d);
+        add_l(T.x * e.x, T.y * e.y, T.z * e.z);
+    } else if (prim & LPT_LIGHT_BIT) {
+        const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + (prim & ~LPT_LIGHT_BIT));
+        const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
+        const float Le = lo4.w;
+        g_n = mk3(n4.x, n4.y, n4.z);
+        float w = 1.0f;
+        const float pdf_prev = load_o().w;   // emitter hits are rare: the origin record is read only here
+        if (pdf_prev >= 0.0f) {
+            float cl = -dot(mk3(n4.x, n4.y, n4.z), d);
+            float area = 4.0f * (t4.w * b4.w);
+            float pl = ((h4.x * h4.x) / (cl * area)) * inv_nl;
+            float pb2 = pdf_prev * pdf_prev;
+            w = pb2 / (pb2 + pl * pl);
+        }
+        float k = Le * w;
+        add_l(T.x * k, T.y * k, T.z * k);
+    } else {
+        const float hu = h4.y, hv = h4.z;
+        const float4 *tv = sc.tri_verts + kTriRec * (size_t)prim;
+        const float4 P0 = tv[0], N0 = tv[1], P1 = tv[2], N1 = tv[3], P2 = tv[4], N2 = tv[5];
+        const float4 mc = tv[6], mp = tv[7];
+        float bw = (1.0f - hu) - hv;
+        const f3 p0 = mk3(P0.x, P0.y, P0.z), p1 = mk3(P1.x, P1.y, P1.z), p2 = mk3(P2.x, P2.y, P2.z);
+        f3 P = mk3((p0.x * bw + p1.x * hu) + p2.x * hv, (p0.y * bw + p1.y * hu) + p2.y * hv, (p0.z * bw + p1.z * hu) + p2.z * hv);
+        f3 Ng = cross(p1 - p0, p2 - p0);
+        float l2 = dot(Ng, Ng);
+        if (l2 > 0.0f) {
+            out.is_surface = true;
+            Ng = Ng * (1.0f / sqrtf(l2));
+            f3 Ns = mk3((N0.x * bw + N1.x * hu) + N2.x * hv, (N0.y * bw + N1.y * hu) + N2.y * hv, (N0.z * bw + N1.z * hu) + N2.z * hv);
+            float n2 = dot(Ns, Ns);
+            Ns = n2 > 0.0f ? Ns * (1.0f / sqrtf(n2)) : Ng;
+            if (dot(Ng, d) > 0.0f) Ng = neg(Ng);
+            if (dot(Ns, Ng) < 0.0f) Ns = neg(Ns);
+            float tu = (P0.w * bw + P1.w * hu) + P2.w * hv;
+            float tvv = (N0.w * bw + N1.w * hu) + N2.w * hv;
+            f3 base = mk3(mc.x, mc.y, mc.z);
+            float rough = mp.x, metal = mp.y;
+            const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
+            if ((atex >> 30) == 1u) {   // kPairedBit set, not LPT_INVALID_INDEX: both textures of the material from one set of taps
+                f3 alb;
+                float mg, mb;
+                texture_lookup_pair(sc, s_lut, atex & ~kPairedBit, mtex, tu, tvv, alb, mg, mb);
+                base.x *= alb.x; base.y *= alb.y; base.z *= alb.z;
+                rough *= mg; metal *= mb;
+            } else {
+                if (atex < sc.n_images) {
+                    const float4 tex = texture_lookup(sc, s_lut, atex, tu, tvv, true);
+                    base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
+                }
+                if (mtex < sc.n_images) {
+                    const float4 tex = texture_lookup(sc, s_lut, mtex, tu, tvv, false);
+                    rough *= tex.y; metal *= tex.z;
+                }
+            }
+            g_n = Ns; g_P = P;
+            g_alb = mk3(clampf(base.x, 0.0f, 1.0f), clampf(base.y, 0.0f, 1.0f), clampf(base.z, 0.0f, 1.0f));
+            const Surface sf = make_surface(base, rough, metal);
+            const f3 V = neg(d);
+            const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
+            const float pspec = spec_probability(sf, NoV);
+            const uint32_t x = pxy & 0x1FFFu, y = (pxy >> 13) & 0x1FFFu, sample = pxy >> 26;
+            const uint32_t pixel = y * p.width + x;
+            const uint32_t seed_counter = seed_base + sample * p.max_bounces;
+            Rng rg = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_SHADE);
+            float r0 = rng_next(rg), r1 = rng_next(rg), r2 = rng_next(rg);
+            float r3 = rng_next(rg), r4 = rng_next(rg), r5 = rng_next(rg);
+            noise_shift(nz, x, y, seed_counter, r4, r5);
+            float am = max2(max2(fabsf(P.x), fabsf(P.y)), fabsf(P.z));
+            float eps = 1.0e-4f * (1.0f + am);
+            const f3 Po = mk3(P.x + Ng.x * eps, P.y + Ng.y * eps, P.z + Ng.z * eps);
+            // next-event estimation
+            if (sc.n_lights) {
+                uint32_t li = (uint32_t)(r0 * (float)sc.n_lights);
+                if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
+                const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + li);
+                const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
+                const float Le = lo4.w, hw = t4.w, hh = b4.w;
+                float a = (2.0f * r1 - 1.0f) * hw, bq = (2.0f * r2 - 1.0f) * hh;
+                f3 qp = mk3((lo4.x + t4.x * a) + b4.x * bq, (lo4.y + t4.y * a) + b4.y * bq, (lo4.z + t4.z * a) + b4.z * bq);
+                f3 w = qp - Po;
+                float d2 = dot(w, w);
+                if (Le > 0.0f && d2 > 0.0f) {
+                    float dist = sqrtf(d2);
+                    f3 wi = w * (1.0f / dist);
+                    float cl = -dot(mk3(n4.x, n4.y, n4.z), wi);
+                    if (cl > 0.0f) {
+                        f3 f;
+                        float pb;
+                        bsdf_eval(sf, Ns, Ng, V, NoV, pspec, wi, f, pb);
+                        if (pb > 0.0f) {
+                            float area = 4.0f * (hw * hh);
+                            float pl = (d2 / (cl * area)) * inv_nl;
+                            float pl2 = pl * pl;
+                            float wm = pl2 / (pl2 + pb * pb);
+                            float NoL = dot(Ns, wi);
+                            float k = ((NoL * Le) * wm) / pl;
+                            f3 contrib = mk3((T.x * f.x) * k, (T.y * f.y) * k, (T.z * f.z) * k);
+                            if (contrib.x > 0.0f || contrib.y > 0.0f || contrib.z > 0.0f) {
+                                out.want_shadow = true;
+                                out.so4 = make_float4(Po.x, Po.y, Po.z, dist * 0.999f);
+                                out.sd4 = make_float4(wi.x, wi.y, wi.z, d4.w);
+                                out.sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
+                            }
+                        }
+                    }
+                }
+            }
+            // BSDF sample -> next ray
+            if (!last_bounce) {
+                f3 Ln, wgt;
+                float pdf;
+                if (bsdf_sample(sf, Ns, Ng, V, NoV, pspec, r3, r4, r5, Ln, wgt, pdf)) {
+                    f3 Tn = mk3(T.x * wgt.x, T.y * wgt.y, T.z * wgt.z);
+                    if (Tn.x > 0.0f || Tn.y > 0.0f || Tn.z > 0.0f) {
+                        out.want_next = true;
+                        out.no4 = make_float4(Po.x, Po.y, Po.z, pdf);
+                        out.nd4 = make_float4(Ln.x, Ln.y, Ln.z, d4.w);
+                        out.nT4 = make_float4(Tn.x, Tn.y, Tn.z, T4.w);
+                    }
+                }
+            }
+        }
+    }
+    if (GBUF && bounce == 0) {
+        const uint32_t gx = pxy & 0x1FFFu, gy = (pxy >> 13) & 0x1FFFu;
+        const size_t px = (size_t)gy * p.width + gx;
+        gb.gbuf[px] = make_uint4(prim, __float_as_uint(h4.x), oct_encode(g_n), pack_albedo(g_alb));
+        float mu = 0.0f, mv = 0.0f, cu, cv, pu, pv;
+        if (prim != 0xFFFFFFFFu && project(gb.cur, g_P, cu, cv) && project(gb.prev, g_P, pu, pv)) { mu = pu - cu; mv = pv - cv; }
+        gb.motion[px] = make_float2(mu, mv);
+    }
+}
+
 template <bool GBUF>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
@@ -1089,176 +1255,195 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
     const bool last_bounce = (uint32_t)bounce + 1u >= p.max_bounces;
     const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride) {
-        bool want_next = false, want_shadow = false, is_surface = false;
-        float4 no4, nd4, nT4, so4, sd4, sc4;
+        ShadeOut so;
+        so.want_next = false; so.want_shadow = false; so.is_surface = false;
         if (i < count) {
             const float4 d4 = ld_nt(qin.d + i), T4 = ld_nt(qin.T + i), h4 = ld_nt(hits + i);
             const uint32_t slot = __float_as_uint(d4.w);
-            const uint32_t pxy = __float_as_uint(T4.w);  // x | y << 13 | sample << 26 (k_raygen)
-            const f3 d = mk3(d4.x, d4.y, d4.z);
-            const f3 T = mk3(T4.x, T4.y, T4.z);
-            const uint32_t prim = __float_as_uint(h4.w);
-            // primary-hit record for the G-buffer (SPEC §15.1); defaults cover miss / emitter / degenerate
-            f3 g_n = neg(d), g_alb = mk3(1.0f, 1.0f, 1.0f);
-            f3 g_P = mk3(0.f, 0.f, 0.f);
-            if (GBUF && bounce == 0) {
-                const float4 o4 = ld_nt(qin.o + i);
-                g_P = mk3(fmaf(d.x, h4.x, o4.x), fmaf(d.y, h4.x, o4.y), fmaf(d.z, h4.x, o4.z));
-            }
-            if (prim == 0xFFFFFFFFu) {
-                const f3 e = env_lookup(probe, d);
-                float4 L = Lsum[slot];
-                L.x = L.x + T.x * e.x; L.y = L.y + T.y * e.y; L.z = L.z + T.z * e.z;
-                Lsum[slot] = L;
-            } else if (prim & LPT_LIGHT_BIT) {
-                const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + (prim & ~LPT_LIGHT_BIT));
-                const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
-                const float Le = lo4.w;
-                g_n = mk3(n4.x, n4.y, n4.z);
-                float w = 1.0f;
-                const float pdf_prev = ld_nt(qin.o + i).w;   // emitter hits are rare: the origin record is read only here
-                if (pdf_prev >= 0.0f) {
-                    float cl = -dot(mk3(n4.x, n4.y, n4.z), d);
-                    float area = 4.0f * (t4.w * b4.w);
-                    float pl = ((h4.x * h4.x) / (cl * area)) * inv_nl;
-                    float pb2 = pdf_prev * pdf_prev;
-                    w = pb2 / (pb2 + pl * pl);
-                }
-                float k = Le * w;
-                float4 L = Lsum[slot];
-                L.x = L.x + T.x * k; L.y = L.y + T.y * k; L.z = L.z + T.z * k;
-                Lsum[slot] = L;
-            } else {
-                const float hu = h4.y, hv = h4.z;
-                const float4 *tv = sc.tri_verts + kTriRec * (size_t)prim;
-                const float4 P0 = tv[0], N0 = tv[1], P1 = tv[2], N1 = tv[3], P2 = tv[4], N2 = tv[5];
-                const float4 mc = tv[6], mp = tv[7];
-                float bw = (1.0f - hu) - hv;
-                const f3 p0 = mk3(P0.x, P0.y, P0.z), p1 = mk3(P1.x, P1.y, P1.z), p2 = mk3(P2.x, P2.y, P2.z);
-                f3 P = mk3((p0.x * bw + p1.x * hu) + p2.x * hv, (p0.y * bw + p1.y * hu) + p2.y * hv, (p0.z * bw + p1.z * hu) + p2.z * hv);
-                f3 Ng = cross(p1 - p0, p2 - p0);
-                float l2 = dot(Ng, Ng);
-                if (l2 > 0.0f) {
-                    is_surface = true;
-                    Ng = Ng * (1.0f / sqrtf(l2));
-                    f3 Ns = mk3((N0.x * bw + N1.x * hu) + N2.x * hv, (N0.y * bw + N1.y * hu) + N2.y * hv, (N0.z * bw + N1.z * hu) + N2.z * hv);
-                    float n2 = dot(Ns, Ns);
-                    Ns = n2 > 0.0f ? Ns * (1.0f / sqrtf(n2)) : Ng;
-                    if (dot(Ng, d) > 0.0f) Ng = neg(Ng);
-                    if (dot(Ns, Ng) < 0.0f) Ns = neg(Ns);
-                    float tu = (P0.w * bw + P1.w * hu) + P2.w * hv;
-                    float tvv = (N0.w * bw + N1.w * hu) + N2.w * hv;
-                    f3 base = mk3(mc.x, mc.y, mc.z);
-                    float rough = mp.x, metal = mp.y;
-                    const uint32_t atex = __float_as_uint(mp.z), mtex = __float_as_uint(mp.w);
-                    if ((atex >> 30) == 1u) {   // kPairedBit set, not LPT_INVALID_INDEX: both textures of the material from one set of taps
-                        f3 alb;
-                        float mg, mb;
-                        texture_lookup_pair(sc, s_lut, atex & ~kPairedBit, mtex, tu, tvv, alb, mg, mb);
-                        base.x *= alb.x; base.y *= alb.y; base.z *= alb.z;
-                        rough *= mg; metal *= mb;
-                    } else {
-                        if (atex < sc.n_images) {
-                            const float4 tex = texture_lookup(sc, s_lut, atex, tu, tvv, true);
-                            base.x *= tex.x; base.y *= tex.y; base.z *= tex.z;
-                        }
-                        if (mtex < sc.n_images) {
-                            const float4 tex = texture_lookup(sc, s_lut, mtex, tu, tvv, false);
-                            rough *= tex.y; metal *= tex.z;
-                        }
-                    }
-                    g_n = Ns; g_P = P;
-                    g_alb = mk3(clampf(base.x, 0.0f, 1.0f), clampf(base.y, 0.0f, 1.0f), clampf(base.z, 0.0f, 1.0f));
-                    const Surface sf = make_surface(base, rough, metal);
-                    const f3 V = neg(d);
-                    const float NoV = max2(dot(Ns, V), LPT_MIN_NOV);
-                    const float pspec = spec_probability(sf, NoV);
-                    const uint32_t x = pxy & 0x1FFFu, y = (pxy >> 13) & 0x1FFFu, sample = pxy >> 26;
-                    const uint32_t pixel = y * p.width + x;
-                    const uint32_t seed_counter = seed_base + sample * p.max_bounces;
-                    Rng rg = rng_init(pixel, stage_seed(p.user_seed, seed_counter), LPT_TAG_SHADE);
-                    float r0 = rng_next(rg), r1 = rng_next(rg), r2 = rng_next(rg);
-                    float r3 = rng_next(rg), r4 = rng_next(rg), r5 = rng_next(rg);
-                    noise_shift(nz, x, y, seed_counter, r4, r5);
-                    float am = max2(max2(fabsf(P.x), fabsf(P.y)), fabsf(P.z));
-                    float eps = 1.0e-4f * (1.0f + am);
-                    const f3 Po = mk3(P.x + Ng.x * eps, P.y + Ng.y * eps, P.z + Ng.z * eps);
-                    // next-event estimation
-                    if (sc.n_lights) {
-                        uint32_t li = (uint32_t)(r0 * (float)sc.n_lights);
-                        if (li > sc.n_lights - 1u) li = sc.n_lights - 1u;
-                        const float4 *Lt = reinterpret_cast<const float4 *>(sc.lights + li);
-                        const float4 n4 = Lt[0], t4 = Lt[1], b4 = Lt[2], lo4 = Lt[3];
-                        const float Le = lo4.w, hw = t4.w, hh = b4.w;
-                        float a = (2.0f * r1 - 1.0f) * hw, bq = (2.0f * r2 - 1.0f) * hh;
-                        f3 qp = mk3((lo4.x + t4.x * a) + b4.x * bq, (lo4.y + t4.y * a) + b4.y * bq, (lo4.z + t4.z * a) + b4.z * bq);
-                        f3 w = qp - Po;
-                        float d2 = dot(w, w);
-                        if (Le > 0.0f && d2 > 0.0f) {
-                            float dist = sqrtf(d2);
-                            f3 wi = w * (1.0f / dist);
-                            float cl = -dot(mk3(n4.x, n4.y, n4.z), wi);
-                            if (cl > 0.0f) {
-                                f3 f;
-                                float pb;
-                                bsdf_eval(sf, Ns, Ng, V, NoV, pspec, wi, f, pb);
-                                if (pb > 0.0f) {
-                                    float area = 4.0f * (hw * hh);
-                                    float pl = (d2 / (cl * area)) * inv_nl;
-                                    float pl2 = pl * pl;
-                                    float wm = pl2 / (pl2 + pb * pb);
-                                    float NoL = dot(Ns, wi);
-                                    float k = ((NoL * Le) * wm) / pl;
-                                    f3 contrib = mk3((T.x * f.x) * k, (T.y * f.y) * k, (T.z * f.z) * k);
-                                    if (contrib.x > 0.0f || contrib.y > 0.0f || contrib.z > 0.0f) {
-                                        want_shadow = true;
-                                        so4 = make_float4(Po.x, Po.y, Po.z, dist * 0.999f);
-                                        sd4 = make_float4(wi.x, wi.y, wi.z, d4.w);
-                                        sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.f);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    // BSDF sample -> next ray
-                    if (!last_bounce) {
-                        f3 Ln, wgt;
-                        float pdf;
-                        if (bsdf_sample(sf, Ns, Ng, V, NoV, pspec, r3, r4, r5, Ln, wgt, pdf)) {
-                            f3 Tn = mk3(T.x * wgt.x, T.y * wgt.y, T.z * wgt.z);
-                            if (Tn.x > 0.0f || Tn.y > 0.0f || Tn.z > 0.0f) {
-                                want_next = true;
-                                no4 = make_float4(Po.x, Po.y, Po.z, pdf);
-                                nd4 = make_float4(Ln.x, Ln.y, Ln.z, d4.w);
-                                nT4 = make_float4(Tn.x, Tn.y, Tn.z, T4.w);
-                            }
-                        }
-                    }
-                }
-            }
-            if (GBUF && bounce == 0) {
-                const uint32_t gx = pxy & 0x1FFFu, gy = (pxy >> 13) & 0x1FFFu;
-                const size_t px = (size_t)gy * p.width + gx;
-                gb.gbuf[px] = make_uint4(prim, __float_as_uint(h4.x), oct_encode(g_n), pack_albedo(g_alb));
-                float mu = 0.0f, mv = 0.0f, cu, cv, pu, pv;
-                if (prim != 0xFFFFFFFFu && project(gb.cur, g_P, cu, cv) && project(gb.prev, g_P, pu, pv)) { mu = pu - cu; mv = pv - cv; }
-                gb.motion[px] = make_float2(mu, mv);
-            }
+            shade_hit<GBUF>(sc, probe, nz, p, s_lut, (uint32_t)bounce, last_bounce, seed_base, inv_nl, gb, d4, T4, h4,
+                            [&]() { return ld_nt(qin.o + i); },
+                            [&](float r, float g, float b) {
+                                float4 L = Lsum[slot];
+                                L.x = L.x + r; L.y = L.y + g; L.z = L.z + b;
+                                Lsum[slot] = L;
+                            }, so);
         }
         // `sorted` (wave-uniform; bit 0: next-bounce queue, bit 1: shadow queue): the queue leaves the block ordered by direction octant
-        const uint32_t si = (sorted & 2) ? block_compact_binned(want_shadow, want_shadow ? dir_octant(sd4.x, sd4.y, sd4.z) : 0u, &ctr->shcount[bounce], lds)
-                                   : block_compact(want_shadow, &ctr->shcount[bounce], lds);
-        if (want_shadow) { st_nt(sq.o + si, so4); st_nt(sq.d + si, sd4); st_nt(sq.c + si, sc4); }
+        const uint32_t si = (sorted & 2) ? block_compact_binned(so.want_shadow, so.want_shadow ? dir_octant(so.sd4.x, so.sd4.y, so.sd4.z) : 0u, &ctr->shcount[bounce], lds)
+                                   : block_compact(so.want_shadow, &ctr->shcount[bounce], lds);
+        if (so.want_shadow) { st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
         if (!last_bounce) {
-            const uint32_t ni = (sorted & 1) ? block_compact_binned(want_next, want_next ? dir_octant(nd4.x, nd4.y, nd4.z) : 0u, &ctr->qcount[bounce + 1], lds)
-                                       : block_compact(want_next, &ctr->qcount[bounce + 1], lds);
-            if (want_next) { st_nt(qout.o + ni, no4); st_nt(qout.d + ni, nd4); st_nt(qout.T + ni, nT4); }
+            const uint32_t ni = (sorted & 1) ? block_compact_binned(so.want_next, so.want_next ? dir_octant(so.nd4.x, so.nd4.y, so.nd4.z) : 0u, &ctr->qcount[bounce + 1], lds)
+                                       : block_compact(so.want_next, &ctr->qcount[bounce + 1], lds);
+            if (so.want_next) { st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
         }
-        n_surface += is_surface ? 1u : 0u;
+        n_surface += so.is_surface ? 1u : 0u;
     }
     // surface-hit count: wave reduce, one atomic per wave per LAUNCH
     for (int off = 32; off > 0; off >>= 1) n_surface += __shfl_down(n_surface, off);
     if ((threadIdx.x & 63u) == 0 && n_surface) atomicAdd(&ctr->shaded[bounce], n_surface);
+}
+
+// ------------------------------------------------------------------ the path kernel: every bounce of a wavefront in ONE launch
+// The per-bounce launches above (reference renderer.rs:484-509: one dispatch per pass and bounce) make the whole chip wait for the
+// longest ray of every bounce: seventeen dependent launches per wavefront, each with its own start-up and drain.  For a full frame
+// (8 M rays per launch) the drains are a few per cent; for a tile shard of a multi-GPU frame (1 M rays) they are half of the time
+// (DESIGN §5.5).  k_path removes the barrier: a LANE carries a path from its primary hit (k_raygen + k_trace_packet have run) to its
+// end — shade, trace the shadow ray, trace the next ray, shade ... — and the wave refills the lanes whose path ended with the next
+// primary hits of its chunk.  No queue between the bounces, no compaction, no hit records: the path state stays in registers.
+//   * traversal is k_trace's step machine (ray_step_pipe, LDS stacks); a lane remembers whether its ray is the shadow ray (any-hit) of
+//     its path or the next closest-hit ray, and traces them in that order, so the additions to the path's radiance happen in the order
+//     of the per-bounce launches (shadow deposit of bounce b before anything of bounce b + 1): the frame is theirs bit for bit;
+//   * shading runs in BATCHES: the lanes whose closest-hit ray has finished wait until at least `64 - refill` lanes want shading (or
+//     as many as are still tracing), so the shading code — three dependent fetches and ~400 instructions — runs for a third of
+//     the wave at a time instead of once per finishing lane;
+//   * nothing waits for another wave (no spinning on queues that another wave fills): a wave ends when its head has no chunk left
+//     and its lanes are done, so the launch cannot deadlock whatever else shares the chip.
+// LDS per wave: the traversal stacks, the sRGB table (1 KB), per-bounce counters (lpt_renderer_get_ray_counts / get_queue_counts).
+// 4 waves per SIMD (128 VGPRs; the allocator wants 150 and spills 15 dwords per lane around the shading batch): measured on a 1 M-ray
+// tile shard, 8 / 12 / 16 waves per CU -> 4.28 / 3.22 / 2.70 ms — the kernel is latency-bound and occupancy is worth more than the spills
+// cost (profiles/r04_experiments_ab.txt)
+#ifndef LPT_PATH_ATTR
+#define LPT_PATH_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+constexpr uint32_t kPathLdsExtra = 1024u + 3u * kMaxBounces * 4u;   // sRGB table + counters: what a wave needs besides its stacks
+template <bool GBUF, bool STATS>
+__global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue q0, const float4 *hits0, float4 *Lsum,
+                                                      FrameCounters *ctr, uint32_t seed0, GBufArgs gb, int refill) {
+    static_assert(kTraceBlock == 64, "one wave per block: the LDS hand-overs below are ordered by the wave's own program order");
+    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
+    const uint32_t stack_bytes = sc.stack_entries * kTraceBlock * (uint32_t)sizeof(uint2);
+    float *s_lut = reinterpret_cast<float *>(lds_dyn + stack_bytes);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_dyn + stack_bytes + 1024u);   // [3][kMaxBounces]: next rays, shadow rays, surface hits per bounce
+    const uint32_t lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_lut[lane + 64u * k] = sc.srgb_lut[lane + 64u * k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_cnt[lane + 64u * k] = 0u;   // kMaxBounces == 64
+    __syncthreads();
+    ChunkPuller pl;
+    puller_init(pl, &ctr->ihead[0], ctr->qcount[0]);
+    const uint32_t nb = p.max_bounces;
+    const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
+    const int min_batch = 64 - refill;
+    uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
+    uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;
+    RayState rs;
+    rs.o = mk3(0.f, 0.f, 0.f); rs.d = mk3(0.f, 0.f, 1.f);
+    ray_begin(rs, rs.o, rs.d, 0.0f);
+    // 0: no path, 1: tracing (shadow: the path's shadow ray, else its next closest-hit ray), 2: closest hit found, waits for shading
+    uint32_t phase = 0u;
+    bool shadow = false, has_next = false;
+    uint32_t bounce = 0u, vslot = 0u, pxy = 0u;
+    float pdf = -1.0f;
+    f3 T = mk3(0.f, 0.f, 0.f), L = mk3(0.f, 0.f, 0.f), nd = mk3(0.f, 0.f, 0.f), cs = mk3(0.f, 0.f, 0.f);
+    for (;;) {
+        const unsigned long long amask = __ballot(phase == 1u);
+        const unsigned long long wmask = __ballot(phase == 2u);
+        const int n_active = __popcll(amask), n_wait = __popcll(wmask);
+        puller_pull(pl);                                   // wave-uniform; a no-op while the chunk in hand lasts or the head is dry
+        const bool more = pl.next < pl.end;
+        const int n_eff = more ? 64 - n_active : n_wait;   // lanes a batch would shade: idle lanes get a new path first
+        if (n_eff > 0 && (n_eff >= min_batch || n_eff >= n_active)) {
+            for (int rep = 0; rep < 2; ++rep) {            // a chunk that ends inside the batch: the rest of the idle lanes start on the next one
+                puller_pull(pl);
+                const unsigned long long imask = __ballot(phase == 0u);
+                if (!(pl.next < pl.end) || imask == 0ull) break;
+                const uint32_t idx = pl.next + (uint32_t)__popcll(imask & ((1ull << lane) - 1ull));
+                if (phase == 0u && idx < pl.end) {
+                    const float4 d4 = ld_nt(q0.d + idx), h4 = ld_nt(hits0 + idx);
+                    pxy = __float_as_uint(q0.T[idx].w);
+                    rs.o = p.origin; rs.d = mk3(d4.x, d4.y, d4.z);
+                    rs.best.t = h4.x; rs.best.u = h4.y; rs.best.v = h4.z; rs.best.prim = __float_as_uint(h4.w);
+                    vslot = __float_as_uint(d4.w);
+                    T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
+                    pdf = -1.0f; bounce = 0u;
+                    phase = 2u;
+                }
+                pl.next = min(pl.end, pl.next + (uint32_t)__popcll(imask));
+            }
+            if (phase == 2u) {
+                ShadeOut so;
+                const float4 d4 = make_float4(rs.d.x, rs.d.y, rs.d.z, __uint_as_float(vslot));
+                const float4 T4 = make_float4(T.x, T.y, T.z, __uint_as_float(pxy));
+                const float4 h4 = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
+                shade_hit<GBUF>(sc, probe, nz, p, s_lut, bounce, bounce + 1u >= nb, seed0 + bounce + 1u, inv_nl, gb, d4, T4, h4,
+                                [&]() { return make_float4(rs.o.x, rs.o.y, rs.o.z, pdf); },
+                                [&](float r, float g, float b) { L.x = L.x + r; L.y = L.y + g; L.z = L.z + b; }, so);
+                if (so.is_surface) atomicAdd(&s_cnt[128u + bounce], 1u);
+                if (so.want_shadow) atomicAdd(&s_cnt[64u + bounce], 1u);
+                if (so.want_next) {
+                    atomicAdd(&s_cnt[bounce + 1u], 1u);
+                    T = mk3(so.nT4.x, so.nT4.y, so.nT4.z);
+                    pdf = so.no4.w;
+                    nd = mk3(so.nd4.x, so.nd4.y, so.nd4.z);
+                }
+                has_next = so.want_next;
+                if (so.want_shadow) {
+                    ray_begin(rs, mk3(so.so4.x, so.so4.y, so.so4.z), mk3(so.sd4.x, so.sd4.y, so.sd4.z), so.so4.w);
+                    cs = mk3(so.sc4.x, so.sc4.y, so.sc4.z);
+                    shadow = true;
+                    phase = 1u;
+                } else if (so.want_next) {
+                    ray_begin(rs, mk3(so.no4.x, so.no4.y, so.no4.z), nd, LPT_T_INF);
+                    shadow = false;
+                    bounce++;
+                    phase = 1u;
+                } else {
+                    Lsum[vslot] = make_float4(L.x, L.y, L.z, 0.0f);
+                    phase = 0u;
+                }
+            }
+        }
+        if (__ballot(phase != 0u) == 0ull) {
+            if (pl.dry) break;
+            continue;
+        }
+        uint32_t dn = 0, dt = 0;
+        if (STATS) {
+            w_steps++;
+            w_live += (uint32_t)__popcll(__ballot(phase == 1u));
+            w_node += (uint32_t)__popcll(__ballot(phase == 1u && rs.tg2.y == 0u && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0)));
+        }
+        if (phase == 1u && ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt)) {
+            if (shadow) {
+                if (rs.best.prim == 0xFFFFFFFFu) { L.x = L.x + cs.x; L.y = L.y + cs.y; L.z = L.z + cs.z; }   // unoccluded: deposit the light sample
+                if (has_next) {
+                    ray_begin(rs, rs.o, nd, LPT_T_INF);   // the next ray leaves the point the shadow ray left
+                    shadow = false;
+                    bounce++;
+                } else {
+                    Lsum[vslot] = make_float4(L.x, L.y, L.z, 0.0f);
+                    phase = 0u;
+                }
+            } else {
+                intersect_lights(sc, rs.o, rs.d, rs.best);
+                phase = 2u;
+            }
+        }
+        if (STATS) {
+            w_tri += (uint32_t)__popcll(__ballot(dt != 0u));
+            if (shadow) { s_nodes += dn; s_tris += dt; } else { n_nodes += dn; n_tris += dt; }
+        }
+    }
+    __syncthreads();
+    if (lane >= 1u && lane <= nb && s_cnt[lane]) atomicAdd(&ctr->qcount[lane], s_cnt[lane]);
+    if (lane < nb) {
+        if (s_cnt[64u + lane]) atomicAdd(&ctr->shcount[lane], s_cnt[64u + lane]);
+        if (s_cnt[128u + lane]) atomicAdd(&ctr->shaded[lane], s_cnt[128u + lane]);
+    }
+    if (STATS) {
+        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
+        atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
+        if (lane == 0) {
+            atomicAdd(&ctr->wave_steps, (unsigned long long)w_steps);
+            atomicAdd(&ctr->live_lanes, (unsigned long long)w_live);
+            atomicAdd(&ctr->node_lanes, (unsigned long long)w_node);
+            atomicAdd(&ctr->tri_lanes, (unsigned long long)w_tri);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ accumulation (SPEC §13)

@@ -27,7 +27,7 @@ def look(origin, direction):
 
 
 def render_hip(dev, glb, width, height, bounces, frames, seed=0, rank=0, world=1, light=None, probe=CORNELL_PROBE,
-               eye=CORNELL_EYE, direction=CORNELL_DIR, raw_accum=False):
+               eye=CORNELL_EYE, direction=CORNELL_DIR, raw_accum=False, options=None):
     """reset_accumulation(); accumulate = true; frames x raytrace(); read back.  Returns (radiance, ray counts)."""
     scene = api.Scene()
     api.loaders.load_gltf(glb, scene)
@@ -40,6 +40,8 @@ def render_hip(dev, glb, width, height, bounces, frames, seed=0, rank=0, world=1
     r.set_max_bounces(bounces)
     r.set_seed(seed)
     r.set_vfov(VFOV)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
     if world > 1:
         r.set_shard(rank, world)
         r.set_resources(dev, sg, pr)

@@ -38,3 +38,14 @@ def device():
     dev = lp.Device(0)
     yield dev
     dev.close()
+
+
+@pytest.fixture(params=["path", "per_bounce"])
+def pipeline(request, monkeypatch):
+    """Runs a test body over both forms of the frame pipeline: every bounce behind the primary hits in ONE launch (k_path, whatever the
+    size of the wavefront) and the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace).  The library picks between them by
+    the wavefront's ray count (LPT_OPT_PATH_RAYS); both must give the oracle's frame at every size.  Modules opt in with
+    `pytestmark = pytest.mark.usefixtures("pipeline")`."""
+    from loupiote_amd import api
+    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF if request.param == "path" else 0})
+    return request.param

@@ -15,7 +15,7 @@ from loupiote_amd import testing as T
 from oracle import gltf_oracle as G, orc
 from test_loader import _jpeg, make_gltf, png_bytes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over k_path and over the per-bounce launches
 
 
 def _grid(nx, nz, size, y, bump, seed):

@@ -10,7 +10,7 @@ import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
 from oracle import harness
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over k_path and over the per-bounce launches
 W, H, DEPTH = 203, 117, 5
 
 
@@ -26,13 +26,15 @@ def cornell(device, cornell_glb):
     sg.close()
 
 
-def _renderer(device, sg, pr, max_fused, lanes=None, size=(W, H)):
+def _renderer(device, sg, pr, max_fused, lanes=None, size=(W, H), options=None):
     r = lp.Renderer(device, size)
     r.downsample_factor = 1.0
     r.resize(device, sg, pr, size)
     r.set_max_bounces(DEPTH)
     r.set_vfov(T.VFOV)
     r.set_max_fused(max_fused)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
     if lanes:
         r.set_lanes(lanes)
     r.reset_accumulation()
@@ -167,16 +169,13 @@ def test_atrium_frame_of_the_unchanged_caller_equals_the_batched_frame(device):
 
 
 def _cut_renderer(device, sg, pr, monkeypatch, rays, size, lanes):
-    """an automatic renderer whose submissions are cut into wavefronts of about `rays` rays (LPT_WAVEFRONT_RAYS is read at creation)"""
-    monkeypatch.setenv("LPT_WAVEFRONT_RAYS", str(rays))
-    r = _renderer(device, sg, pr, 0, lanes, size=size)
-    monkeypatch.delenv("LPT_WAVEFRONT_RAYS")
-    return r
+    """an automatic renderer whose submissions are cut into wavefronts of about `rays` rays (lpt_renderer_set_option)"""
+    return _renderer(device, sg, pr, 0, lanes, size=size, options={"wavefront_rays": rays})
 
 
 @pytest.mark.parametrize("size,lanes", [((203, 117), 2), ((203, 117), 1), ((256, 128), 2), ((97, 301), 3)])
 def test_a_large_batch_is_cut_into_runs_of_tile_rows_and_read_back_piece_by_piece(device, cornell, monkeypatch, size, lanes):
-    """a recorded batch of more than ~4 M rays (here: of more than LPT_WAVEFRONT_RAYS) leaves as several wavefronts, each a run of tile
+    """a recorded batch of more than ~4 M rays (here: of more than LPT_OPT_WAVEFRONT_RAYS) leaves as several wavefronts, each a run of tile
     rows with ALL the samples; read_radiance has each run copied to the host behind its own accumulation.  Bit for bit the
     frame of one wavefront, of eager launches, and of the ordinary read path; frames that continue an accumulation too."""
     _, sg, pr = cornell
@@ -257,24 +256,24 @@ def test_read_pixels_and_blit_of_a_recorded_frame_travel_piece_by_piece_too(devi
     ref.close()
 
 
-def test_both_traversal_steps_give_the_oracle_frame(device, cornell, cornell_glb, monkeypatch):
-    """k_trace's default step makes one memory round trip (kernels.h ray_step_pipe: the triangle tested in a step was found by an
-    earlier one) and bounce 0 is traced by packet traversal (k_trace_packet: one tree walk per 64 coherent rays); LPT_PIPE_RAYS=0
-    selects the two-round-trip step, LPT_PACKET=0 per-ray traversal for bounce 0 too, LPT_MERGE_TRACE=0 the split k_intersect /
-    k_shadow launches.  The order of the tests differs, the frame and the ray counts do not."""
+def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_glb):
+    """The default: bounce 0 by packet traversal (k_trace_packet: one tree walk per 64 coherent rays), then — for a wavefront this small —
+    every later bounce in ONE launch (k_path); path_rays = 0 selects the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace, one
+    memory round trip per traversal step: ray_step_pipe), pipe_rays = 0 their two-round-trip step, packet_primary = 0 per-ray traversal
+    for bounce 0 too, merge_trace = 0 the split k_intersect / k_shadow launches.  The order of the tests differs, the frame and the ray
+    counts do not (lpt_renderer_set_option: no environment variable selects a kernel)."""
     _, sg, pr = cornell
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
-    for env in ({}, {"LPT_PIPE_RAYS": "0"}, {"LPT_PIPE_RAYS": "30000"}, {"LPT_MERGE_TRACE": "0"}, {"LPT_PACKET": "0"}, {"LPT_PACKET": "0", "LPT_PIPE_RAYS": "0"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        r = _renderer(device, sg, pr, 0)
-        for k in env:
-            monkeypatch.delenv(k)
+    variants = ({}, {"path_rays": 0}, {"path_rays": 0, "pipe_rays": 0}, {"path_rays": 0, "pipe_rays": 30000}, {"merge_trace": 0}, {"packet_primary": 0},
+                {"packet_primary": 0, "pipe_rays": 0}, {"path_waves_per_cu": 3, "path_refill": 20}, {"path_refill": 63}, {"path_refill": 0})
+    for opts in variants:
+        r = _renderer(device, sg, pr, 0, options=opts)
+        assert all(r.get_option(k) == v for k, v in opts.items())
         for _ in range(4):
             r.raytrace(view)
-        assert r.read_radiance().tobytes() == ref.tobytes(), env
+        assert r.read_radiance().tobytes() == ref.tobytes(), opts
         c = r.ray_counts()
-        assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded), env
-        assert c.primary == (0 if ("LPT_PACKET" in env or "LPT_MERGE_TRACE" in env) else 4 * W * H), env   # which kernel traced bounce 0
+        assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded), opts
+        assert c.primary == (0 if ("packet_primary" in opts or "merge_trace" in opts) else 4 * W * H), opts   # which kernel traced bounce 0
         r.close()

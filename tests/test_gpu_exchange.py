@@ -15,7 +15,7 @@ import pytest
 import loupiote_amd as lp
 from loupiote_amd import testing as T
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over k_path and over the per-bounce launches
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -28,12 +28,14 @@ def _setup(device, glb):
     return sg, pr
 
 
-def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8), weights=None):
+def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8), weights=None, options=None):
     r = lp.Renderer(device, (w, h))
     r.downsample_factor = 1.0
     r.resize(device, sg, pr, (w, h))
     r.set_max_bounces(bounces)
     r.set_vfov(T.VFOV)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
     if world > 1:
         r.set_shard(rank, world, tile[0], tile[1], weights=weights)
         r.set_resources(device, sg, pr)
@@ -199,9 +201,8 @@ def test_sharded_frames_cut_into_runs_of_tiles_equal_one_gpu(device, cornell_glb
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     w, h = 203, 117
     one = _renderer(device, sg, pr, w, h, 4)
-    monkeypatch.setenv("LPT_WAVEFRONT_RAYS", "6000")          # about five 32x8 tiles of 4 samples per wavefront
-    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, (32, 8), weights) for q in range(world)]
-    monkeypatch.delenv("LPT_WAVEFRONT_RAYS")
+    cut = {"wavefront_rays": 6000}          # about five 32x8 tiles of 4 samples per wavefront
+    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, (32, 8), weights, options=cut) for q in range(world)]
     for frame in range(2):
         for _ in range(4):
             one.raytrace(view)

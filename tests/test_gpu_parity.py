@@ -80,11 +80,12 @@ def test_tile_shards_sum_to_full_frame(device, cornell_glb):
     assert closest == fc.closest
 
 
-def test_split_and_merged_traversal_launches_agree(device, cornell_glb, monkeypatch):
-    """LPT_MERGE_TRACE=0 (IntersectorPass and the shadow pass as separate launches, k_intersect / k_shadow) and the
-    default (k_trace: both in one persistent launch) give the same bits and the same ray counts"""
-    merged, cm = T.render_hip(device, cornell_glb, 160, 96, 6, 3)
-    monkeypatch.setenv("LPT_MERGE_TRACE", "0")     # read when the renderer is created
-    split, cs = T.render_hip(device, cornell_glb, 160, 96, 6, 3)
-    assert merged.tobytes() == split.tobytes()
-    assert (cm.closest, cm.shadow, cm.shaded) == (cs.closest, cs.shadow, cs.shaded)
+def test_split_and_merged_traversal_launches_agree(device, cornell_glb):
+    """merge_trace = 0 (IntersectorPass and the shadow pass as separate launches, k_intersect / k_shadow), the merged per-bounce
+    launches (k_trace: both in one persistent launch) and the path kernel (every bounce in one launch) give the same bits and the
+    same ray counts"""
+    merged, cm = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"path_rays": 0})
+    split, cs = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"merge_trace": 0})
+    path, cp = T.render_hip(device, cornell_glb, 160, 96, 6, 3)
+    assert merged.tobytes() == split.tobytes() == path.tobytes()
+    assert (cm.closest, cm.shadow, cm.shaded) == (cs.closest, cs.shadow, cs.shaded) == (cp.closest, cp.shadow, cp.shaded)
