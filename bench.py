@@ -80,6 +80,10 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: path_rays, "
                     "path_waves_per_cu, path_refill, pipe_rays, packet_primary, merge_trace, refill, trace_waves_per_cu, shade_blocks_per_cu, wavefront_rays); every value gives the same frame")
     ap.add_argument("--no-shard-emulation", action="store_true", help="skip the shard_emulation leg (rank 0's 1/2, 1/4, 1/8 tile shard of the frame on this GPU)")
+    ap.add_argument("--blit-mode", choices=["pathtrace", "temporal", "denoised"], default="pathtrace",
+                    help="BlitMode of every renderer (renderer.rs:160-167).  temporal / denoised: every raytrace() is a frame of the ASVGF pipeline (BASELINE config 5's form) — "
+                         "on N>1 each call is followed by its exchange of the filter inputs and rank 0 filters; the tile weight is calibrated with the filter in the frame")
+    ap.add_argument("--group-bracket", action="store_true", help="tests: every exchange inside lpt_comm_group_begin / lpt_comm_group_end (the form a host driving several GPUs from one thread uses)")
     ap.add_argument("--eager", action="store_true", help="experiments: every raytrace() launches at once (lpt_renderer_set_max_fused(1), the round-2 behaviour)")
     ap.add_argument("--max-fused", type=int, default=0, help="experiments: lpt_renderer_set_max_fused(n) on the timed renderer (0 = the library's default)")
     ap.add_argument("--lanes", type=int, default=0, help="experiments: wavefront lanes of the timed renderer (0 = the library's default)")
@@ -327,6 +331,15 @@ def run(args):
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
 
     weights = [None]   # tile-ownership weights of the ranks (None = equal shares), the same on every rank
+    blit_mode = {"pathtrace": lp.BlitMode.Pahtrace, "temporal": lp.BlitMode.Temporal, "denoised": lp.BlitMode.DenoisedPathrace}[args.blit_mode]
+    denoising = blit_mode != lp.BlitMode.Pahtrace
+
+    def exchange(rr):
+        if args.group_bracket:
+            lp.Comm.group_begin()
+        rr.exchange(xmode)
+        if args.group_bracket:
+            lp.Comm.group_end()
 
     def make_renderer(comm=None, lanes=None, shard=None):
         shard = shard or args.emulate_shard
@@ -339,6 +352,8 @@ def run(args):
         rr.resize(dev, sg, probe, (WIDTH, HEIGHT))
         rr.set_max_bounces(DEPTH)
         rr.set_vfov(T.VFOV)
+        if blit_mode != lp.BlitMode.Pahtrace:
+            rr.set_blit_mode(blit_mode)
         if comm is not None:
             rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)
@@ -366,8 +381,10 @@ def run(args):
         r.accumulate = True                      # app.rs:318
         for _ in range(SPP):
             r.raytrace(view)                     # records; the four calls leave together at the next submission point
-        if comms:
-            r.exchange(xmode)                    # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
+            if comms and denoising:
+                exchange(r)                      # a denoising call is a frame of its own: its filter inputs travel, rank 0 filters
+        if comms and not denoising:
+            exchange(r)                          # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
         if rank == 0:
             last["img"] = r.read_radiance(out=dst)   # blocking: the end of the §8d span
         else:
@@ -394,19 +411,24 @@ def run(args):
             t_frame = (time.perf_counter() - tc) / CAL * 1e3
             tm = r.timings()
             r.enable_timings(False)
+            # rank 0's extra = its frame beyond the mean tracing time of the ranks: unpack, resolve, read-back — and, in the denoising modes, the filter
             t_tr = sum(tm.get(k, (0.0, 0))[0] for k in ("ray generation", "primary intersection", "intersection", "shading", "shadow", "path", "accumulation")) / CAL
             tt_ = torch.tensor([t_tr], dtype=torch.float64)
             dist.all_reduce(tt_, op=dist.ReduceOp.SUM)
             t_tr_mean = float(tt_.item()) / world
             c0 = max(0.0, t_frame - t_tr_mean)
             share0 = 1.0 - c0 * (world - 1) / max(world * t_tr_mean, 1e-9)      # rank 0's share relative to an equal share
-            w0 = max(1, min(8, int(round(8.0 * share0))))
+            w0 = max(0 if denoising else 1, min(8, int(round(8.0 * share0))))   # the denoising modes may leave rank 0 as a pure compositor / filter
             calib = {"frame_ms_equal_shares": t_frame, "trace_ms_mean": t_tr_mean, "rank0_extra_ms": c0, "share0": share0}
         box = [w0]
         dist.broadcast_object_list(box, src=0)                                   # every rank uses rank 0's figure
         w0 = int(box[0])
-        if w0 != 8:
-            weights[0] = [w0] + [8] * (world - 1)
+        # the weights of a communicator may sum to at most 64 (kMaxVirtual): beyond 8 ranks the others' weight shrinks with the world size
+        # (and past 32 ranks — kMaxWorld for weighted shards — the shares stay equal)
+        base = max(1, min(8, 64 // max(world, 1)))
+        w0 = max(0, min(base, int(round(w0 * base / 8.0))))
+        if w0 != base and world <= 32:
+            weights[0] = [w0] + [base] * (world - 1)
             r.close()
             r = make_renderer(comms[0], lanes=args.lanes or None)
             if args.max_fused:
@@ -551,7 +573,7 @@ def run(args):
             for _ in range(SPP):
                 r.raytrace(view)
             if comms:
-                r.exchange(xmode)
+                exchange(r)
             r.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
@@ -611,7 +633,7 @@ def run(args):
             rr.accumulate = True
             rr.raytrace_n(view, SPP)      # == SPP x { raytrace(view); accumulate = true } as one wavefront, submitted at once
             if comms:
-                rr.exchange(xmode)
+                exchange(rr)
 
         for _ in range(2 * FPS):
             tp_frame()

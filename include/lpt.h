@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LPT_ABI_VERSION 4u
+#define LPT_ABI_VERSION 5u
 
 /* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
 #define LPT_INVALID_INDEX 0xFFFFFFFFu
@@ -117,6 +117,11 @@ typedef struct lpt_accel_stats {
     uint32_t host_baked_triangles; /* triangles transformed to world space on the HOST by the last upload (0 for
                                       LPT_ACCEL_BUILD_GPU_LBVH: instances are baked by k_bake_instance on the device) */
     float upload_ms;               /* wall time of the whole lpt_scene_upload(_ex) call: bake + build + copies */
+    /* ABI 5: texel bytes this scene keeps in device memory — the tiled atlas (every image some material samples on its own, or none
+     * references) + the paired (albedo, mra) texels of the materials whose two textures have one size; an image that only ever
+     * appears as half of a pair is stored once, in the pair (the reference keeps each image once: scene.rs:172-184) */
+    uint32_t texture_pairs;
+    uint64_t texture_bytes_resident;
 } lpt_accel_stats;
 
 /* result of a closest-hit query (the build's `Intersection`, 16 bytes) */
@@ -271,6 +276,8 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
  * Rendered results are identical. */
 #define LPT_ACCEL_BUILD_HOST_SAH 0u
 #define LPT_ACCEL_BUILD_GPU_LBVH 1u
+/* or-ed into `flags`: do not interleave the (albedo, mra) textures of a material (experiments; the frame does not change by a bit) */
+#define LPT_UPLOAD_NO_TEXTURE_PAIRS 0x100u
 int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags, lpt_scene_gpu **out);
 int lpt_scene_gpu_destroy(lpt_scene_gpu *sg);
 /* replaces: Instance::set_transform + a new SceneGPU (crates/standalone/src/lib.rs:118-121, scene.rs:151):

@@ -45,7 +45,8 @@ class SceneCounts(C.Structure):
 class AccelStats(C.Structure):
     _fields_ = [("triangles", C.c_uint32), ("nodes", C.c_uint32), ("node_bytes", C.c_uint32),
                 ("tri_bytes", C.c_uint32), ("max_depth", C.c_uint32), ("build_ms", C.c_float),
-                ("host_baked_triangles", C.c_uint32), ("upload_ms", C.c_float)]
+                ("host_baked_triangles", C.c_uint32), ("upload_ms", C.c_float),
+                ("texture_pairs", C.c_uint32), ("texture_bytes_resident", C.c_uint64)]
 
 
 class RayCounts(C.Structure):

@@ -94,6 +94,16 @@ class Comm:
         _check(A.lib().lpt_comm_info(self._h, C.byref(r), C.byref(w)))
         return r.value, w.value
 
+    @staticmethod
+    def group_begin():
+        """ncclGroupStart for a thread that drives several communicators: the exchanges inside the bracket are issued together"""
+        _check(A.lib().lpt_comm_group_begin())
+
+    @staticmethod
+    def group_end():
+        """the outermost end issues the RCCL operations and then enqueues what consumes the received data"""
+        _check(A.lib().lpt_comm_group_end())
+
     def close(self):
         if self._h:
             A.lib().lpt_comm_destroy(self._h)
@@ -224,11 +234,13 @@ class SceneGPU:
         self._dev = device
 
     @classmethod
-    def new_from_scene(cls, scene, device, gpu_build=False):
+    def new_from_scene(cls, scene, device, gpu_build=False, pair_textures=True):
         """scene.rs:151 `SceneGPU::new_from_scene`; gpu_build=True builds the BVH on the GPU (Morton radix tree, a few
-        ms, lower quality) instead of the host SAH builder — for scenes that are rebuilt every frame"""
+        ms, lower quality) instead of the host SAH builder — for scenes that are rebuilt every frame; pair_textures=False
+        keeps every image on its own in the atlas (LPT_UPLOAD_NO_TEXTURE_PAIRS; experiments: the frame is the same)"""
         h = C.c_void_p()
-        _check(A.lib().lpt_scene_upload_ex(device.inner(), scene._h, 1 if gpu_build else 0, C.byref(h)))
+        flags = (1 if gpu_build else 0) | (0 if pair_textures else 0x100)
+        _check(A.lib().lpt_scene_upload_ex(device.inner(), scene._h, flags, C.byref(h)))
         return cls(h, device)
 
     def stats(self):
@@ -447,6 +459,8 @@ class Renderer:
     def set_comm(self, comm, weights=None):
         """bind a `Comm` (None unbinds); implies set_shard(rank, world, 32, 8, weights)"""
         w = None if weights is None else np.ascontiguousarray(weights, np.uint32)
+        if w is not None and (comm is None or w.size != comm.info()[1]):
+            raise Error(A.LPT_ERR_INVALID_ARG, "set_comm: one weight per rank of the communicator")   # the C side reads weights[0 .. world)
         _check(A.lib().lpt_renderer_set_comm_weighted(self._h, comm._h if comm is not None else None, A.ptr(w)))
 
     def exchange(self, mode=A.EXCHANGE_GATHER_TILES):

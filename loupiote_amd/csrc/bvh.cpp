@@ -22,6 +22,17 @@
 
 #include "common.h"
 
+// Builder A/B knobs exist only in builds made with -DLPT_EXPERIMENTS (csrc/Makefile `variant`): the shipped library reads no
+// environment variable that changes what it builds.
+static inline const char *lpt_experiment_env(const char *name) {
+#ifdef LPT_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 namespace lpt {
 
 // SPEC §6 — computed in double, rounded to fp32 once.
@@ -340,7 +351,7 @@ struct Collapse {
     std::vector<uint8_t> how;    // i == 1: 1 = 8-wide node, 0 = leaf;  i >= 2: 0 = same as C(n,i-1), else k of D(n,i)
     std::vector<uint8_t> k8;     // k of D(n,8), used when n becomes an 8-wide node
     explicit Collapse(const std::vector<BuildNode> &nodes) : n(nodes), C(7 * nodes.size()), how(7 * nodes.size(), 0), k8(nodes.size(), 0) {
-        if (const char *ev = getenv("LPT_BVH_PRIM_COST")) { const float v = (float)atof(ev); if (v > 0.f) kPrimCost = v; }
+        if (const char *ev = lpt_experiment_env("LPT_BVH_PRIM_COST")) { const float v = (float)atof(ev); if (v > 0.f) kPrimCost = v; }
         for (size_t id = nodes.size(); id-- > 0;) {
             const BuildNode &b = n[id];
             const float A = b.box.half_area();
@@ -439,7 +450,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         r.prim = t;
     }
     b.nodes.reserve(2 * (size_t)n);
-    const char *mode = getenv("LPT_BVH_COLLAPSE");  // "greedy" keeps the round-1 builder for A/B runs
+    const char *mode = lpt_experiment_env("LPT_BVH_COLLAPSE");  // "greedy" keeps the round-1 builder for A/B runs
     const bool use_dp = !(mode && strcmp(mode, "greedy") == 0);
     b.leaf_max = use_dp ? 1u : kLeafMax;
     b.build(0, n, 0);
@@ -449,7 +460,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         // traversal time for 3x the (host) build time; more passes add little (profiles/r03_experiments_ab.txt)
         int passes = 4;
         float fraction = 0.3f;
-        if (const char *ev = getenv("LPT_BVH_REINSERT")) { float f = fraction; const int got = sscanf(ev, "%d,%f", &passes, &f); if (got == 2 && f > 0.f && f <= 1.f) fraction = f; }
+        if (const char *ev = lpt_experiment_env("LPT_BVH_REINSERT")) { float f = fraction; const int got = sscanf(ev, "%d,%f", &passes, &f); if (got == 2 && f > 0.f && f <= 1.f) fraction = f; }
         if (passes > 0) {
             Reinserter opt(b.nodes);
             opt.run(std::min(passes, 64), fraction);
@@ -595,7 +606,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         if (out.nodes.size() < queue.size()) out.nodes.resize(queue.size());
         out.nodes[w] = node;
     }
-    if (getenv("LPT_BVH_STATS")) {
+    if (lpt_experiment_env("LPT_BVH_STATS")) {
         fprintf(stderr, "[lpt bvh] %s: %zu nodes, depth %u, SAH %.3f, children/node:", use_dp ? "dp" : "greedy", out.nodes.size(), max_depth,
                 sah / std::max((double)b.nodes[0].box.half_area(), 1e-30));
         for (int i = 1; i <= 8; ++i) fprintf(stderr, " %u", stat_kids[i]);

@@ -121,6 +121,9 @@ struct lpt_scene_gpu {
     void *pair_texels = nullptr, *pair_images = nullptr;
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> pair_map;
     std::vector<DImage> pair_descs;   // host copy: a paired material's record carries its pair's offset and size directly
+    // which images the tiled atlas holds on their own: an image that only ever appears as half of a pair is not stored a second
+    // time (scene.rs:172-184 keeps each image once)
+    std::vector<uint8_t> image_resident;
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
     void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
@@ -203,8 +206,9 @@ struct lpt_renderer {
     uint32_t rank = 0, world = 1, tile_w = 32, tile_h = 8;
     std::vector<uint32_t> weights;   // tile-ownership weights of the ranks (empty = every rank 1: tile id mod world)
     ShardMap map{1u, 1u, {0u}};      // this rank's part of the ownership rule
-    ShardTable h_table{};            // rank 0: the whole rule (staging offsets of the ranks) ...
-    ShardTable *d_table = nullptr;   // ... and its copy in device memory for the unpack kernels; refreshed by alloc_frame_buffers
+    ShardTable h_table{};            // rank 0: the whole rule ...
+    std::vector<uint32_t> h_offset;  // ... the staging offsets of the ranks (world + 1 entries, any world size) ...
+    ShardTable *d_table = nullptr;   // ... and the rule's copy in device memory for the unpack kernels; refreshed by alloc_frame_buffers
     bool use_noise = false, stats = false, timings = false;
     // traversal tuning (lpt_renderer_set_option, for experiments)
     int refill = 44;
@@ -415,14 +419,24 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
 #undef SCR
 }
 
-// the material as the shading records carry it: a material whose albedo and mra textures were paired at upload names the pair
-static lpt_material device_material(const lpt_scene_gpu *sg, const lpt_material &m) {
+// The material as the shading records carry it: a material whose albedo and mra textures were paired at upload names the pair.
+// Every other texture id is an index into the atlas or LPT_INVALID_INDEX: an id beyond the images means "no texture" (SPEC §9, as
+// the oracle reads it) and must not reach the kernel as a value it would take for the paired encoding.  `ok` = false:
+// the material samples an image on its own that the atlas does not hold (it was only known as half of a pair at upload time).
+static lpt_material device_material(const lpt_scene_gpu *sg, const lpt_material &m, bool *ok = nullptr) {
     lpt_material d = m;
+    if (ok) *ok = true;
     const auto it = sg->pair_map.find(std::make_pair(m.albedo_texture, m.mra_texture));
     if (it != sg->pair_map.end()) {
         const DImage &di = sg->pair_descs[it->second];
         d.albedo_texture = kPairedBit | di.offset;          // in 8-byte texels, < 2^30
         d.mra_texture = di.width | (di.height << 16);       // both <= 65535 (checked when the pair is built)
+        return d;
+    }
+    uint32_t *ids[2] = {&d.albedo_texture, &d.mra_texture};
+    for (uint32_t *id : ids) {
+        if (*id >= sg->image_resident.size()) *id = LPT_INVALID_INDEX;
+        else if (!sg->image_resident[*id] && ok) *ok = false;
     }
     return d;
 }
@@ -439,7 +453,9 @@ static int make_bake_args(const lpt_scene_gpu *sg, const lpt_scene &scene, size_
     a.c[3] = a02 * a21 - a01 * a22; a.c[4] = a00 * a22 - a02 * a20; a.c[5] = a01 * a20 - a00 * a21;
     a.c[6] = a01 * a12 - a02 * a11; a.c[7] = a02 * a10 - a00 * a12; a.c[8] = a00 * a11 - a01 * a10;
     a.vertex_offset = e.vertex_offset; a.index_offset = e.index_offset; a.first_tri = first; a.n_tris = n;
-    const lpt_material dm = device_material(sg, scene.materials[now.material_index < scene.materials.size() ? now.material_index : 0u]);
+    bool resident = true;
+    const lpt_material dm = device_material(sg, scene.materials[now.material_index < scene.materials.size() ? now.material_index : 0u], &resident);
+    if (!resident) return fail(LPT_ERR_INVALID_ARG, "instance %zu now samples a texture on its own that was uploaded only as half of an (albedo, mra) pair: upload the scene again", i);
     memcpy(a.mat, &dm, 32);
     return LPT_OK;
 }
@@ -517,7 +533,9 @@ int lpt_scene_upload(lpt_device *dev, const lpt_scene *scene, lpt_scene_gpu **ou
 
 int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags, lpt_scene_gpu **out) {
     if (!dev || !scene || !out) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload: null");
-    if (flags > LPT_ACCEL_BUILD_GPU_LBVH) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload_ex: unknown flags %u", flags);
+    if ((flags & ~LPT_UPLOAD_NO_TEXTURE_PAIRS) > LPT_ACCEL_BUILD_GPU_LBVH) return fail(LPT_ERR_INVALID_ARG, "lpt_scene_upload_ex: unknown flags %u", flags);
+    const bool pair_textures = !(flags & LPT_UPLOAD_NO_TEXTURE_PAIRS);
+    flags &= ~LPT_UPLOAD_NO_TEXTURE_PAIRS;
     HIP_TRY(hipSetDevice(dev->ordinal));
     const auto t_upload = std::chrono::steady_clock::now();
     Accel acc;
@@ -558,12 +576,13 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     // Paired textures: a material that has both an albedo and an mra texture of one size gets the two interleaved — 8 B per texel
     // (albedo RGBA8, mra RGBA8) in apron tiles of 128 B — so that ONE set of four taps, in ONE cache line, serves both lookups of a shaded hit:
     // 1 line per hit instead of 2 x 1.4 (1.56 with plain 4x4 tiles) (k_shade is bound by HBM traffic, most of it texels).  Lossless: the taps and
-    // the filter arithmetic are those of two separate lookups.  The separate images stay in the atlas for every other use.
+    // the filter arithmetic are those of two separate lookups.  An image that some material samples on its own (no partner, a partner
+    // of another size, another partner's pair over the budget) also stays in the tiled atlas; one that only ever appears as half of a
+    // pair does not (scene.rs:172-184: each image once) — `image_resident`.
     std::vector<DImage> pair_descs;
     std::vector<uint64_t> pair_texels;
     {
-        const char *ev = getenv("LPT_PAIR_TEXTURES");
-        const bool enable = !ev || atoi(ev) != 0;
+        const bool enable = pair_textures;
         const size_t budget = (size_t)1 << 30;   // bytes of paired texels per scene
         for (const lpt_material &m : scene->materials) {
             if (!enable) break;
@@ -594,6 +613,15 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
             pair_descs.push_back(di);
             sg->pair_descs.push_back(di);
         }
+        // an image no material references is kept: a later material edit (lpt_scene_gpu_update_instances) may start to sample it
+        std::vector<uint8_t> referenced(scene->images.size(), 0), alone(scene->images.size(), 0);
+        for (const lpt_material &m : scene->materials) {
+            const bool paired = sg->pair_map.count(std::make_pair(m.albedo_texture, m.mra_texture)) != 0;
+            for (uint32_t id : {m.albedo_texture, m.mra_texture})
+                if (id < scene->images.size()) { referenced[id] = 1; if (!paired) alone[id] = 1; }
+        }
+        sg->image_resident.assign(scene->images.size(), 1);
+        for (size_t i = 0; i < scene->images.size(); ++i) sg->image_resident[i] = (!referenced[i] || alone[i]) ? 1 : 0;
     }
     if (!gpu_build) {
         UP(nodes, acc.nodes)
@@ -616,11 +644,17 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     UP(lights, scene->lights)
     std::vector<DImage> descs;
     std::vector<uint8_t> texels;
-    for (const Image &im : scene->images) {
+    for (size_t ii = 0; ii < scene->images.size(); ++ii) {
+        const Image &im = scene->images[ii];
         // texels are stored in 8x4-texel tiles of 128 B (one cache line): the 2x2 bilinear footprint then touches
         // 1.4 lines on average instead of 2 (k_shade is bound by L2-miss traffic); `pad` = tiles per row
         DImage di;
         di.offset = (uint32_t)(texels.size() / 4);
+        if (!sg->image_resident[ii]) {   // only ever half of a pair: lives in pair_texels, no shading record carries its id
+            di.width = di.height = di.pad = 0u;
+            descs.push_back(di);
+            continue;
+        }
         di.width = im.width; di.height = im.height;
         const uint32_t tx = (im.width + 7u) / 8u, ty = (im.height + 3u) / 4u;
         di.pad = tx;
@@ -686,6 +720,8 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     sg->stats.max_depth = acc.max_depth;
     sg->stats.build_ms = acc.build_ms;
     sg->stats.host_baked_triangles = gpu_build ? 0u : n_tris;
+    sg->stats.texture_bytes_resident = (uint64_t)texels.size() + 8u * (uint64_t)pair_texels.size();
+    sg->stats.texture_pairs = (uint32_t)pair_descs.size();
     if (gpu_build) {
         // bake every instance on the device (fp32 transform, cofactor normals, binary64 Woop maps: bit-identical to the
         // host bake), then build the tree there
@@ -1032,17 +1068,31 @@ static uint32_t owned_tiles(const ShardMap &m, uint32_t n_tiles) {
     for (uint32_t j = 0; j < m.w; ++j) n += tiles_of_virtual(n_tiles, m.V, m.vlist[j]);
     return n;
 }
-static ShardTable make_shard_table(const std::vector<uint32_t> &weights, uint32_t world, uint32_t n_tiles, uint32_t area) {
+// `offsets` (world + 1 entries, any world size): where every rank's slots start in rank 0's staging area — the host's copy of the rule.
+// The device table holds arrays only for a WEIGHTED rule (world <= kMaxWorld, sum of weights <= kMaxVirtual: checked by the callers);
+// unit weights are the closed form on both sides (the fixed-size arrays were written for any world).
+static ShardTable make_shard_table(const std::vector<uint32_t> &weights, uint32_t world, uint32_t n_tiles, uint32_t area, std::vector<uint32_t> &offsets) {
     ShardTable t{};
+    offsets.assign((size_t)world + 1u, 0u);
+    if (weights.empty()) {
+        t.V = world;
+        t.unit_world = world;
+        for (uint32_t q = 0; q <= world; ++q) offsets[q] = shard_slot_offset(n_tiles, world, area, q);
+        return t;
+    }
     const std::vector<uint32_t> owner = deal_virtual_ranks(weights, world);
     t.V = (uint32_t)owner.size();
     std::vector<uint32_t> tiles(world, 0u);
-    for (uint32_t v = 0; v < t.V; ++v) {
+    for (uint32_t v = 0; v < t.V && v < kMaxVirtual; ++v) {
+        if (owner[v] >= kMaxWorld) continue;   // unreachable behind the callers' checks; never write past the arrays
         t.owner[v] = (uint8_t)owner[v];
         t.j[v] = (uint8_t)t.w[owner[v]]++;
         tiles[owner[v]] += tiles_of_virtual(n_tiles, t.V, v);
     }
-    for (uint32_t q = 0; q < world; ++q) t.offset[q + 1] = t.offset[q] + tiles[q] * area;
+    for (uint32_t q = 0; q < world; ++q) {
+        offsets[q + 1] = offsets[q] + tiles[q] * area;
+        if (q < kMaxWorld) t.offset[q + 1] = offsets[q + 1];
+    }
     return t;
 }
 
@@ -1092,7 +1142,7 @@ static int alloc_frame_buffers(lpt_renderer *r) {
     const size_t px = (size_t)r->w * r->h;
     r->n_slots = n_slots;   // the lanes' ray buffers are allocated by the first raytrace() that uses them
     if (r->rank == 0u) {   // a possible root of an exchange (also of a one-rank communicator): the whole ownership rule, for the unpack kernels
-        r->h_table = make_shard_table(r->weights, r->world, n_tiles, r->tile_w * r->tile_h);
+        r->h_table = make_shard_table(r->weights, r->world, n_tiles, r->tile_w * r->tile_h, r->h_offset);
         if (!r->d_table) HIP_TRY(hipMalloc(&r->d_table, sizeof(ShardTable)));
         HIP_TRY(hipMemcpy(r->d_table, &r->h_table, sizeof(ShardTable), hipMemcpyHostToDevice));
     }
@@ -1153,10 +1203,12 @@ int lpt_renderer_destroy(lpt_renderer *r) {
         v.erase(std::remove(v.begin(), v.end(), r), v.end());
     }
     hipStreamSynchronize(r->stream);
+    for (int l = 0; l < kMaxLanes; ++l)   // a wavefront whose second half was never enqueued (a failed submission) is not behind r->stream
+        if (r->wf[l].stream) hipStreamSynchronize(r->wf[l].stream);
     free_frame_buffers(r);
     for (int l = 0; l < kMaxLanes; ++l) {
         Wavefront &wf = r->wf[l];
-        if (wf.stream) { hipStreamSynchronize(wf.stream); hipStreamDestroy(wf.stream); }
+        if (wf.stream) hipStreamDestroy(wf.stream);
         if (wf.done) hipEventDestroy(wf.done);
         if (wf.consumed) hipEventDestroy(wf.consumed);
         if (wf.ctr) hipFree(wf.ctr);
@@ -1740,14 +1792,24 @@ static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
         const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
         return wavefront_finish(r, tk[k % ahead], early ? read : nullptr, std::min(r->h, g0 * r->tile_h), std::min(r->h, g1 * r->tile_h));
     };
+    // A failure part way leaves wavefronts on the lanes' streams whose second halves (the waits that put them behind the renderer's
+    // stream) were never enqueued: wait for them here, so that nothing is still running on buffers a later call frees or reuses
+    auto bail = [&](int st) {
+        for (int l = 0; l < kMaxLanes; ++l) {
+            if (r->wf[l].stream) hipStreamSynchronize(r->wf[l].stream);
+            r->wf[l].consumed_recorded = false;
+        }
+        hipStreamSynchronize(r->stream);
+        return st;
+    };
     for (uint32_t k = 0; k < pieces; ++k) {
-        if (k >= ahead) { const int st = finish(k - ahead); if (st != LPT_OK) return st; }
+        if (k >= ahead) { const int st = finish(k - ahead); if (st != LPT_OK) return bail(st); }
         const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
         r->n_wavefronts++;
         const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule, tk[k % ahead]);
-        if (st != LPT_OK) return st;
+        if (st != LPT_OK) return bail(st);
     }
-    for (uint32_t k = pieces > ahead ? pieces - ahead : 0u; k < pieces; ++k) { const int st = finish(k); if (st != LPT_OK) return st; }
+    for (uint32_t k = pieces > ahead ? pieces - ahead : 0u; k < pieces; ++k) { const int st = finish(k); if (st != LPT_OK) return bail(st); }
     return LPT_OK;
 }
 
@@ -2084,9 +2146,10 @@ int lpt_shard_layout_weighted(uint32_t width, uint32_t height, uint32_t tile_w, 
     uint32_t sum = 0;
     for (uint32_t q = 0; q < world; ++q) { if (weights[q] > kMaxWeight) return fail(LPT_ERR_INVALID_ARG, "weighted shards: weight %u exceeds %u", weights[q], kMaxWeight); sum += weights[q]; }
     if (sum == 0u || sum > kMaxVirtual) return fail(LPT_ERR_INVALID_ARG, "weighted shards: the weights must sum to 1..%u (got %u)", kMaxVirtual, sum);
-    const ShardTable t = make_shard_table(std::vector<uint32_t>(weights, weights + world), world, n_tiles, area);
-    if (out_slots) *out_slots = t.offset[rank + 1] - t.offset[rank];
-    if (out_offset) *out_offset = t.offset[rank];
+    std::vector<uint32_t> off;
+    make_shard_table(std::vector<uint32_t>(weights, weights + world), world, n_tiles, area, off);
+    if (out_slots) *out_slots = off[rank + 1] - off[rank];
+    if (out_offset) *out_offset = off[rank];
     return LPT_OK;
 }
 int lpt_shard_layout(uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h, uint32_t world, uint32_t rank, uint32_t *out_slots, uint32_t *out_offset) {
@@ -2183,9 +2246,9 @@ static int exchange_enqueue(lpt_renderer *r, int mode) {
         if (root) {
             RCCL_TRY(nc.GroupStart());
             for (uint32_t q = 1; q < p.world; ++q) {
-                const uint32_t nq = r->h_table.offset[q + 1] - r->h_table.offset[q];
+                const uint32_t nq = r->h_offset[q + 1] - r->h_offset[q];
                 if (!nq) continue;
-                ncclResult_t e = nc.Recv(stage + 40u * (size_t)r->h_table.offset[q], 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
+                ncclResult_t e = nc.Recv(stage + 40u * (size_t)r->h_offset[q], 40u * (size_t)nq, ncclUint8, (int)q, c->comm, s);
                 if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
             }
             RCCL_TRY(nc.GroupEnd());
@@ -2207,9 +2270,9 @@ static int exchange_enqueue(lpt_renderer *r, int mode) {
     if (root) {
         RCCL_TRY(nc.GroupStart());
         for (uint32_t q = 1; q < p.world; ++q) {
-            const uint32_t nq = r->h_table.offset[q + 1] - r->h_table.offset[q];
+            const uint32_t nq = r->h_offset[q + 1] - r->h_offset[q];
             if (!nq) continue;
-            ncclResult_t e = nc.Recv(r->xstage + r->h_table.offset[q], 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
+            ncclResult_t e = nc.Recv(r->xstage + r->h_offset[q], 4 * (size_t)nq, ncclFloat32, (int)q, c->comm, s);
             if (e != ncclSuccess) { nc.GroupEnd(); return fail(LPT_ERR_RCCL, "ncclRecv from rank %u failed: %s", q, nc.GetErrorString(e)); }
         }
         RCCL_TRY(nc.GroupEnd());
@@ -2230,17 +2293,17 @@ static int exchange_finish(lpt_renderer *r, int mode) {
             hipLaunchKernelGGL(k_unpack_den, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->d_table, reinterpret_cast<unsigned char *>(r->xstage), r->den_noisy, r->den_gbuf[r->den_cur], r->den_motion);
         }
         if (root && r->world != 1u) launch_filter(r, s);   // world == 1: raytrace() has filtered already
-        HIP_TRY(hipGetLastError());
         stage_end(r, s);
+        HIP_TRY(hipGetLastError());
         r->den_inputs_ready = false;
         return LPT_OK;   // the composite has written the local target on rank 0
     }
     if (root && mode == LPT_EXCHANGE_GATHER_TILES) {
         const FrameParams p = shard_params(r);
         hipLaunchKernelGGL(k_unpack_frame, dim3(stream_grid(r, npx)), dim3(kBlock), 0, s, p, r->d_table, r->xstage, r->frame);
-        HIP_TRY(hipGetLastError());
     }
     stage_end(r, s);
+    HIP_TRY(hipGetLastError());
     r->presented = root;
     return LPT_OK;
 }
@@ -2295,7 +2358,7 @@ int lpt_renderer_exchange(lpt_renderer *r, int mode) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     if (r->timings) { r->ring_pos++; harvest_slot(r, cur_slot(r)); }
     int st = exchange_enqueue(r, mode);
-    if (st != LPT_OK) return st;
+    if (st != LPT_OK) { stage_end(r, r->stream); return st; }   // a failed exchange still closes its timing stage (get_timings after a failure)
     if (t_group_depth > 0) {   // the RCCL operations are only issued by the outermost lpt_comm_group_end: finish there
         t_deferred.push_back(DeferredFinish{r, mode});
         return LPT_OK;
@@ -2344,7 +2407,7 @@ int lpt_renderer_exchange_local(lpt_renderer *root, lpt_renderer *const *peers, 
             if (den) hipLaunchKernelGGL(k_pack_den, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->den_noisy, q->den_gbuf[q->den_cur], q->den_motion, reinterpret_cast<unsigned char *>(q->xstage));
             else hipLaunchKernelGGL(k_pack_owned, dim3(stream_grid(q, pq.n_slots)), dim3(kBlock), 0, q->stream, pq, q->accum, q->xstage);
             // the stand-in of ncclSend / ncclRecv inside one process: a (peer) copy into the root's staging area
-            HIP_TRY(hipMemcpyPeerAsync(stage0 + bps * (size_t)root->h_table.offset[pq.rank], root->dev->ordinal, q->xstage, q->dev->ordinal,
+            HIP_TRY(hipMemcpyPeerAsync(stage0 + bps * (size_t)root->h_offset[pq.rank], root->dev->ordinal, q->xstage, q->dev->ordinal,
                                        bps * (size_t)pq.n_slots, q->stream));
         }
         if (den) q->den_inputs_ready = false;

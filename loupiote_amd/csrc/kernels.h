@@ -91,8 +91,11 @@ struct ShardMap {
 };
 // rank 0's view of the same rule, for the unpack kernels: virtual rank -> (owner, position in the owner's list), and where
 // every rank's slots start in the staging area
+// Unit weights (any world size) use the closed form — owner = tile % world, shard_slot_offset — and leave the arrays unused:
+// `unit_world` != 0 says so.  The arrays only ever hold a WEIGHTED rule, which lpt_renderer_set_shard_weighted limits to kMaxWorld ranks.
 struct ShardTable {
     uint32_t V;
+    uint32_t unit_world;
     uint8_t owner[kMaxVirtual], j[kMaxVirtual];
     uint32_t w[kMaxWorld];
     uint32_t offset[kMaxWorld + 1];   // in slots; offset[world] = all slots
@@ -755,13 +758,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
 // five / three consecutive 16-byte scalar loads from a wave-uniform address (the compiler keeps uniform loads of memory it cannot
 // prove unwritten on the vector path: 64 lanes fetching one address)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sload_node(const void *p, uint4 &a, uint4 &b, uint4 &c, uint4 &d, uint4 &e) {
-    u32x4 va, vb, vc, vd, ve;
-    asm volatile("s_load_dwordx4 %0, %5, 0x0\n\ts_load_dwordx4 %1, %5, 0x10\n\ts_load_dwordx4 %2, %5, 0x20\n\t"
-                 "s_load_dwordx4 %3, %5, 0x30\n\ts_load_dwordx4 %4, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(va), "=&s"(vb), "=&s"(vc), "=&s"(vd), "=&s"(ve) : "s"(p) : "memory");
-    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w); c = make_uint4(vc.x, vc.y, vc.z, vc.w);
-    d = make_uint4(vd.x, vd.y, vd.z, vd.w); e = make_uint4(ve.x, ve.y, ve.z, ve.w);
+// the node's header (origin, exponents, imask; child / triangle base, meta bytes): the 48 plane bytes behind it reach the lanes through LDS
+__device__ __forceinline__ void sload_node_header(const void *p, uint4 &a, uint4 &b) {
+    u32x4 va, vb;
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(va), "=&s"(vb) : "s"(p) : "memory");
+    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w);
 }
 __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, float4 &c) {
     u32x4 va, vb, vc;
@@ -783,7 +785,10 @@ __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, f
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
     // LDS of the wave: the 48 child planes of the node in hand as floats (192 B), then the stack of node indices — 7 siblings per
-    // level + the path: (7 * depth + 8) entries (host)
+    // level + the path: (7 * depth + 8) entries (host).  ONE wave per block: the hand-overs through `planes` and `stk` below are
+    // ordered by the wave's own program order (LDS operations of a wave complete in order) plus the barriers that keep the compiler
+    // from moving them; with more than one wave per block they would race.
+    static_assert(kTraceBlock == 64, "k_trace_packet: planes[] and stk[] are per-wave LDS, the block must be one wave");
     float *planes = reinterpret_cast<float *>(lds_dyn);
     uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn) + 48;
     // read-only for the whole launch and never aliased by what the kernel writes: lets the uniform fetches below become scalar loads
@@ -801,7 +806,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
         const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
         const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
         Hit best;
-        best.t = live ? LPT_T_INF : 0.0f; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;   // a dead lane's interval [0, 0] meets nothing
+        best.t = live ? LPT_T_INF : -1.0f; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;   // a dead lane's interval [0, -1] is empty: it enters nothing
         // where this lane finds its near / far planes among the node's 48 (qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]): fixed per ray
         const uint32_t onx = negx ? 24u : 0u, ofx = negx ? 0u : 24u, ony = negy ? 32u : 8u, ofy = negy ? 8u : 32u, onz = negz ? 40u : 16u, ofz = negz ? 16u : 40u;
         // visit order: the first lane's octant stands for the packet
@@ -810,10 +815,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
         uint32_t node_index = 0;
         bool have = true;
         while (have) {
-            uint4 n0, n1, n2, n3, n4;
-            sload_node(nodes + node_index, n0, n1, n2, n3, n4);   // wave-uniform address
+            uint4 n0, n1;
+            sload_node_header(nodes + node_index, n0, n1);   // wave-uniform address
             // the 48 quantised planes are the same for every lane: lane j converts plane j — ONE conversion instruction for the wave
             // instead of 48 — and LDS hands each lane the ones it needs (its near and far plane per axis, four children per read)
+            __syncthreads();   // the previous node's plane reads are done before its planes are overwritten (one wave: no wait, a compiler fence)
             if (lane < 48u) planes[lane] = (float)reinterpret_cast<const uint8_t *>(nodes + node_index)[32u + lane];
             __syncthreads();
             if (STATS) visits++;
@@ -884,6 +890,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
                 sp++;
             }
             have = sp > 0;
+            __syncthreads();   // lane 0's pushes are visible to the pop below
             if (have) { sp--; node_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)stk[sp]); }
         }
         if (live) {
@@ -1484,8 +1491,13 @@ __device__ __host__ __forceinline__ uint32_t shard_slot_offset(uint32_t n_tiles,
 // tile -> (owner, slot of the tile's first pixel in the owner's slot array): the inverse of slot_to_pixel for every owner
 __device__ __forceinline__ void tile_owner(const ShardTable &t, uint32_t tile, uint32_t area, uint32_t &owner, uint32_t &slot0) {
     const uint32_t period = tile / t.V, v = tile - period * t.V;
+    if (t.unit_world) { owner = v; slot0 = period * area; return; }   // tile id mod world
     owner = t.owner[v];
     slot0 = (period * t.w[owner] + t.j[v]) * area;
+}
+// where rank q's slots start in the staging area
+__device__ __forceinline__ uint32_t rank_offset(const ShardTable &t, uint32_t n_tiles, uint32_t area, uint32_t q) {
+    return t.unit_world ? shard_slot_offset(n_tiles, t.unit_world, area, q) : t.offset[q];
 }
 // rank 0: the whole frame from the concatenated slot arrays
 __global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const ShardTable *tp, const float4 *staged, float4 *frame) {
@@ -1498,7 +1510,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_frame(FrameParams p, const Sh
         uint32_t owner, slot0;
         tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
         const uint32_t slot = slot0 + xy_to_within(p, x - tx * p.tile_w, y - ty * p.tile_h);
-        frame[i] = staged[(size_t)st.offset[owner] + slot];
+        frame[i] = staged[(size_t)rank_offset(st, p.n_tiles, area, owner) + slot];
     }
 }
 
@@ -1528,8 +1540,8 @@ __global__ __launch_bounds__(kBlock) void k_unpack_den(FrameParams p, const Shar
         uint32_t owner, slot0;
         tile_owner(st, ty * p.tiles_x + tx, area, owner, slot0);
         const uint32_t slot = slot0 + xy_to_within(p, x - tx * p.tile_w, y - ty * p.tile_h);
-        const uint32_t first = st.offset[owner];
-        const size_t n_owner = st.offset[owner + 1u] - first;
+        const uint32_t first = rank_offset(st, p.n_tiles, area, owner);
+        const size_t n_owner = rank_offset(st, p.n_tiles, area, owner + 1u) - first;
         const unsigned char *base = staged + 40u * (size_t)first;
         noisy[i] = reinterpret_cast<const float4 *>(base)[slot];
         gbuf[i] = reinterpret_cast<const uint4 *>(base + 16u * n_owner)[slot];

@@ -151,3 +151,46 @@ def test_lifecycle_does_not_leak_device_memory(device, cornell_glb):
     device.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < 64 << 20, (free0, free1)      # allocator slack only, no per-cycle growth
+
+
+def test_texture_ids_beyond_the_images_mean_no_texture_and_images_live_once(device):
+    """a texture id in 0x40000000..0x7FFFFFFF is 'no texture' like every id beyond the images (SPEC §9, as the
+    oracle reads it) — it must not reach the kernels as the paired-texel encoding.  VERDICT r03 #8: an image that only ever appears as
+    half of an (albedo, mra) pair is stored once (in the pair), one that some material also samples on its own stays in the atlas; the
+    frame is the oracle's either way, and the same with pairing switched off."""
+    from loupiote_amd import scenes
+    from oracle import harness, orc
+    desc = scenes.synthetic_helmet(texture_size=64)
+    m = desc["materials"]
+    m[2] = (m[2][0], m[2][1], m[2][2], m[2][3], 0x40000010)     # visor: albedo image 4, a bogus mra id inside the paired range
+    m[3] = (m[3][0], m[3][1], m[3][2], 0x7FFFFFFF, 0x50000000)   # polished metal: both ids bogus
+    m[4] = (m[4][0], m[4][1], m[4][2], 0, 0xFFFFFFFF)            # painted: image 0 on its own — it is also half of the shell's pair (0, 1)
+    osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    acc, oc = osc.render(240, 136, view, T.VFOV, 5, frames=3, want_counters=True)
+    want = orc.resolve(acc)
+    sizes = {}
+    for pair in (True, False):
+        sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device, pair_textures=pair)
+        pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+        r = lp.Renderer(device, (240, 136))
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (240, 136))
+        r.set_max_bounces(5)
+        r.set_vfov(T.VFOV)
+        r.reset_accumulation()
+        r.accumulate = True
+        r.reset_ray_counts()
+        for _ in range(3):
+            r.raytrace(view)
+        c = r.ray_counts()
+        assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+        assert r.read_radiance().tobytes() == want.tobytes(), pair
+        st = sg.stats()
+        sizes[pair] = (st.texture_pairs, st.texture_bytes_resident)
+        r.close(); pr.close(); sg.close()
+    one = 64 * 64 * 4                      # a 64x64 RGBA8 image in 8x4 tiles
+    apron = 22 * 22 * 16 * 8               # a 64x64 pair in apron tiles: ceil(64 / 3)^2 tiles of 16 texels of 8 bytes
+    assert sizes[False] == (0, 5 * one)
+    # pairs (0, 1) and (2, 3); images 1, 2, 3 live only in their pairs, image 0 (also sampled alone) and image 4 stay in the atlas
+    assert sizes[True] == (2, 2 * one + 2 * apron)

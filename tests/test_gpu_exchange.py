@@ -45,7 +45,8 @@ def _renderer(device, sg, pr, w, h, bounces, rank=0, world=1, tile=(32, 8), weig
 
 
 @pytest.mark.parametrize("w,h,world,tile", [(200, 120, 2, (32, 8)), (200, 120, 3, (32, 8)), (203, 117, 2, (8, 8)), (97, 61, 5, (16, 8)), (64, 64, 8, (32, 8)),
-                                            (203, 117, 3, (64, 2)), (97, 61, 2, (16, 12))])   # the last two: tile sides that are not multiples of 8 (row-major inside a tile)
+                                            (203, 117, 3, (64, 2)), (97, 61, 2, (16, 12)),   # tile sides that are not multiples of 8 (row-major inside a tile)
+                                            (203, 117, 40, (8, 8)), (97, 61, 70, (8, 8))])   # unit weights, more ranks than the weighted rule's tables hold (32 / 64)
 def test_progressive_frames_exchanged_every_frame_equal_one_gpu(device, cornell_glb, w, h, world, tile):
     """ADVICE r1 (dist.py:38): exchange after EVERY progressive frame; rank 0's presented frame must equal the single-GPU
     frame each time (an in-place reduce into rank 0's accumulation buffer double-counts from the second frame on).

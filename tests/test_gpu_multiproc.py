@@ -2,7 +2,7 @@
 
 Real RCCL refuses two ranks on one device, so the N ranks of `python bench.py --gpus N --oversubscribe` (N processes that share
 GPU 0) exchange through tests/tools/fake_rccl.c — a test stand-in for the eleven librccl entry points the library resolves with
-dlsym (shared-memory mailboxes, synchronous), selected with LPT_RCCL_LIBRARY.  What this covers, for real and not by emulation:
+dlsym (shared-memory messages; asynchronous and stream-ordered, groups defer their operations to the outermost ncclGroupEnd), selected with LPT_RCCL_LIBRARY.  What this covers, for real and not by emulation:
 bench.py's launcher and its N>1 control flow (id rendezvous over gloo, one communicator per renderer, the calibrated tile
 weight, barriers, max over ranks), and the library's exchange with world > 1 in separate processes — every rank's send size
 against rank 0's receive size and staging offset (the stand-in fails on a mismatch), gather and reduce.  The exchanged frame must
@@ -28,6 +28,17 @@ def fake_rccl(tmp_path_factory):
     return so
 
 
+def test_the_stand_in_is_stream_ordered_and_defers_grouped_operations(fake_rccl, tmp_path):
+    """the properties of RCCL an exchange can get wrong (VERDICT r03 #4 iii): operations run in stream order, asynchronously, and an
+    operation recorded inside a group bracket is only enqueued by the OUTERMOST ncclGroupEnd — a consumer enqueued inside the bracket
+    reads the old data (tests/tools/fake_rccl_order.c: two threads = two ranks on GPU 0)"""
+    exe = str(tmp_path / "fake_rccl_order")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "tools", "fake_rccl_order.c"),
+                           "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    p = subprocess.run([exe, fake_rccl], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", (p.stdout, p.stderr)
+
+
 def _bench(extra, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
@@ -48,6 +59,22 @@ def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
         # equal shares, the same number of frames before it: the last timed frame is the single-GPU frame, bit for bit
         assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
         assert j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+
+
+def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processes(fake_rccl):
+    """(i) every exchange inside lpt_comm_group_begin / _end: the stand-in enqueues grouped operations only at the outermost ncclGroupEnd,
+    so a second phase (unpack) enqueued too early would read stale tiles and the checksum would differ.  (ii) BlitMode::Temporal across two
+    processes (BASELINE config 5's form): the filter inputs travel after every call, rank 0 filters, its tile weight is calibrated with
+    the filter in the frame (VERDICT r03 #4 iv) — the presented frame equals the one-process frame bit for bit."""
+    one = _bench(["--no-extras"])
+    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--group-bracket", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    assert j["rccl"]["exchange_frame_complete_on_rank0"] is True and j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
+    t1 = _bench(["--blit-mode", "temporal", "--no-extras", "--no-shard-emulation"])
+    for extra in (["--root-weight", "8"], ["--group-bracket"], ["--exchange", "reduce"]):
+        t2 = _bench(["--gpus", "2", "--oversubscribe", "--blit-mode", "temporal", "--no-extras"] + extra, {"LPT_RCCL_LIBRARY": fake_rccl})
+        assert t2["rccl"]["exchange_frame_complete_on_rank0"] is True, extra
+        assert t2["config"]["frame_checksum"] == t1["config"]["frame_checksum"], extra
+        assert 0 <= t2["rccl"]["tile_weights"][0] <= 8
 
 
 def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):
