@@ -1747,6 +1747,8 @@ static int wavefront_finish(lpt_renderer *r, const Ticket &tk, const ReadPlan *r
             wf.consumed_recorded = true;
         }
         HIP_TRY(hipGetLastError());
+    } else if (r->mode != LPT_BLIT_PATHTRACE) {
+        r->den_inputs_ready = true;   // a rank without tiles (a pure compositor / filter rank) still takes part in the frame's exchange
     }
     if (tk.denoise) r->prev_cam = tk.cur;        // prev_model_to_screen = P * V^-1 (:542-546)
     return LPT_OK;

@@ -18,7 +18,7 @@ def bvh_check(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("bvh") / "bvh_check")
     src = [os.path.join(ROOT, "tests", "tools", "bvh_check.cpp")] + [os.path.join(CSRC, f) for f in
                                                                       ("scene.cpp", "bvh.cpp", "png.cpp", "jpeg.cpp", "gltf.cpp")]
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe] + src + ["-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DLPT_EXPERIMENTS", "-o", exe] + src + ["-lpthread"], check=True)   # LPT_EXPERIMENTS: the builder A/B knobs (LPT_BVH_*) exist in this test build only
     return exe
 
 
