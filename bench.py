@@ -268,6 +268,36 @@ def load_profile_json(name):
     return None
 
 
+def from_profiles_object(avg_launch_ms):
+    """What the bench line REPLAYS from committed profile summaries (profiles/traffic.json, profiles/limits.json: rocprofv3 --pmc passes of an
+    earlier run of the same command, tools/profile.sh) — kept under ONE key so that a reader of the line cannot take it for something
+    this run observed (VERDICT r03 #6).  Returns (object, fabric bytes per k_trace launch or None)."""
+    traffic_j = load_profile_json("traffic.json") or {}
+    limits_j = load_profile_json("limits.json")
+    traffic = traffic_j.get("k_trace_bytes_per_launch")
+    binding = None
+    if limits_j and "valu_issue" in limits_j and "gather_path" in limits_j:
+        binding = {"name": "vector_memory_path", "frac": limits_j["gather_path"]["frac_of_9.7"], "frac_range": [limits_j["gather_path"]["frac_of_13.5"], limits_j["gather_path"]["frac_of_9.7"]],
+                   "valu_issue_frac": limits_j["valu_issue"]["frac"], "lane_efficiency": (limits_j.get("lane_efficiency") or {}).get("k_trace"),
+                   "note": "the kernel's algorithmic bytes come from L1 / L2 / Infinity Cache, not from the HBM `frac` is quoted against; its launch time follows "
+                           "the bytes a ray pulls through the CU's vector-memory path (measured: fewer or cheaper VALU instructions change nothing, more bytes or "
+                           "fewer cached nodes do — DESIGN 5.1), quoted here against the 9.7-13.5 TB/s a fully divergent dwordx4 gather reaches in the "
+                           "microbenchmark; the VALU issue rate against its own microbenchmark ceiling rides along"}
+    obj = {"what": "replayed from committed rocprofv3 --pmc summaries of an earlier run of this command — NOT measured in this run",
+           "source": {"traffic": traffic_j.get("source"), "limits": (limits_j or {}).get("source")},
+           "traffic": traffic, "traffic_unit": "fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE) per k_trace launch",
+           "limits": limits_j, "binding_limit": binding}
+    return obj, traffic
+
+
+def roofline_fractions(achieved_gbps, traffic_bytes, avg_launch_ms):
+    """frac = algorithmic bytes / launch time / 8 TB/s (the contract's figure: served mostly by the caches); frac_fabric = the bytes that crossed
+    the fabric per launch (PMC, replayed) / THIS run's launch time / 8 TB/s — the HBM-side utilisation, never to be quoted without the other."""
+    frac = achieved_gbps / HBM_PEAK_GBS
+    frac_fabric = (traffic_bytes / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic_bytes and avg_launch_ms > 0) else None
+    return frac, frac_fabric
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run(args):
     global WIDTH, HEIGHT, SPP
@@ -686,8 +716,8 @@ def run(args):
 
     out = None
     if rank == 0:
-        traffic_j = load_profile_json("traffic.json") or {}
-        limits_j = load_profile_json("limits.json")
+        profiles_j, fabric_bytes = from_profiles_object(s_avg)
+        rf_frac, rf_frac_fabric = roofline_fractions(s_achieved, fabric_bytes, s_avg)
         out = {
             "metric": baseline_metric(),
             "value": (closest + shadow) / elapsed / 1e6,
@@ -707,6 +737,7 @@ def run(args):
                                    % (accel.triangles, len(desc["images"]), tex_bytes / 1e6, len(desc["materials"]), WIDTH, HEIGHT, SPP, DEPTH, SPP,
                                       "; lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", "pageable" if args.pageable else "page-locked", FPS),
                        "texture_bytes": tex_bytes, "textures": len(desc["images"]), "materials": len(desc["materials"]),
+                       "texture_bytes_resident": int(accel.texture_bytes_resident), "texture_pairs": int(accel.texture_pairs),
                        "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed, "submission": "eager" if args.eager else "record-then-submit",
                        "raytrace_calls_per_frame": (sub1[0] - sub0[0]) / max(args.steps * FPS, 1), "wavefronts_per_frame": (sub1[1] - sub0[1]) / max(args.steps * FPS, 1),
                        "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
@@ -722,8 +753,11 @@ def run(args):
             "shard_emulation": shard_emulation,
             "rccl": rccl,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": s_achieved / HBM_PEAK_GBS,
-                         "traffic": traffic_j.get("k_trace_bytes_per_launch"), "traffic_source": traffic_j.get("source"),
+                         "frac": rf_frac,
+                         # the same launches against the bytes that actually crossed the fabric (replayed counter figure / this run's launch time): the
+                         # HBM-side utilisation.  `frac` says the caches serve the algorithmic bytes as fast as HBM could; this says how busy HBM is.
+                         "frac_fabric": rf_frac_fabric,
+                         "traffic": fabric_bytes, "traffic_is": "from_profiles (replayed, see roofline.from_profiles.source), not measured in this run",
                          "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": s_bytes,
                          "basis": "un-overlapped launches: %d frames issued as one 4-sample wavefront each (lpt_renderer_set_max_fused(4)), one frame at a time, HIP events on the "
                                   "stream the kernel runs on around every k_trace launch — the duration rocprofv3's kernel trace reports for `bench.py --max-fused 4 --lanes 1` "
@@ -733,14 +767,7 @@ def run(args):
                                                   "the chip with the other wavefront's kernels — a scheduling figure, not a kernel figure"},
                          "region": {"achieved": ((closest_l - primary_l) * b_ray + shadow_l * b_sh) / elapsed / 1e9, "frac": ((closest_l - primary_l) * b_ray + shadow_l * b_sh) / elapsed / 1e9 / HBM_PEAK_GBS,
                                     "note": "all k_trace algorithmic bytes of the timed region / its wall time (which also contains k_shade, ray generation, accumulation, the read-back): a lower bound"},
-                         "limits": limits_j,
-                         "binding_limit": ({"name": "vector_memory_path", "frac": limits_j["gather_path"]["frac_of_9.7"], "frac_range": [limits_j["gather_path"]["frac_of_13.5"], limits_j["gather_path"]["frac_of_9.7"]],
-                                            "valu_issue_frac": limits_j["valu_issue"]["frac"], "lane_efficiency": (limits_j.get("lane_efficiency") or {}).get("k_trace"), "source": limits_j.get("source"),
-                                            "note": "the kernel's algorithmic bytes come from L1 / L2 / Infinity Cache, not from the HBM `frac` is quoted against; its launch time follows "
-                                                    "the bytes a ray pulls through the CU's vector-memory path (measured: fewer or cheaper VALU instructions change nothing, more bytes or "
-                                                    "fewer cached nodes do — DESIGN 5.1), quoted here against the 9.7-13.5 TB/s a fully divergent dwordx4 gather reaches in the "
-                                                    "microbenchmark; the VALU issue rate against its own microbenchmark ceiling rides along"}
-                                           if limits_j and "valu_issue" in limits_j and "gather_path" in limits_j else None),
+                         "from_profiles": profiles_j,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),

@@ -76,3 +76,23 @@ def test_graft_entry_has_build_and_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     assert callable(g.build) and callable(g.smoke)
+
+
+def test_replayed_profile_figures_live_under_one_key_and_frac_fabric_rides_with_frac():
+    """what bench.py loads from profiles/*.json (counter passes of an earlier run) sits under roofline.from_profiles and is
+    labelled as replayed; roofline.frac_fabric = fabric bytes per launch / THIS run's launch time / 8 TB/s stands beside roofline.frac"""
+    sys.path.insert(0, ROOT)
+    import bench
+    obj, traffic = bench.from_profiles_object(1.0)
+    assert set(obj) == {"what", "source", "traffic", "traffic_unit", "limits", "binding_limit"} and "NOT measured in this run" in obj["what"]
+    assert traffic == obj["traffic"] and traffic > 1e9 and obj["source"]["traffic"].startswith("profiles/traffic.json")
+    assert obj["binding_limit"]["name"] == "vector_memory_path" and 0 < obj["binding_limit"]["frac"] < 1
+    frac, frac_fabric = bench.roofline_fractions(7990.0, traffic, 1.008)
+    assert abs(frac - 7990.0 / 8000.0) < 1e-12
+    assert abs(frac_fabric - traffic / 1.008e-3 / 1e9 / 8000.0) < 1e-12 and 0.2 < frac_fabric < 0.6
+    assert bench.roofline_fractions(7990.0, None, 1.0)[1] is None
+    # the keys of the roofline object the line carries, as the source states them
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"frac": rf_frac', '"frac_fabric": rf_frac_fabric', '"from_profiles": profiles_j', '"traffic": fabric_bytes', '"shard_emulation": shard_emulation'):
+        assert key in src, key
+    assert '"limits": limits_j,' not in src.split('"roofline": {')[1].split('"from_profiles": profiles_j')[0]   # not beside the live figures any more
