@@ -572,3 +572,68 @@ def test_nee_mis_path_tracer_equals_an_independent_bsdf_only_estimator():
     want = Lsum.mean(axis=0)
     err = Lsum.std(axis=0) / np.sqrt(n)
     assert np.all(np.abs(got - want) <= 4 * err + 0.01 * want), (got, want, err)   # measured: 0.18 % apart at 0.6 % standard error
+
+
+# ---------------------------------------------------------------------------- pins against physics (scenes: tests/kat_scenes.py)
+def _pixel_batches(sc, view, vfov, depth, batches, frames):
+    """mean and standard error of one shading point's radiance from `batches` independent renders of `frames` samples each"""
+    means = []
+    for b in range(batches):
+        acc = sc.render(33, 33, view, vfov, depth, frames=frames, crop=(16, 16, 17, 17), user_seed=1000 + b)
+        means.append(acc[16, 16, :3] / acc[16, 16, 3])
+    means = np.array(means, np.float64)
+    return means.mean(axis=0), means.std(axis=0, ddof=1) / np.sqrt(batches)
+
+
+@pytest.mark.parametrize("base,rough,metal", [((0.8, 0.6, 0.4), 0.5, 0.0), ((0.95, 0.9, 0.8), 0.25, 1.0), ((1.0, 1.0, 1.0), 1.0, 0.0)])
+def test_furnace_of_lights_gives_the_directional_albedo(base, rough, metal):
+    """A convex object inside a CLOSED cube of six emitters of one radiance Le sends Le * a(V) to the camera, a(V) = the BSDF's directional
+    albedo (binary64 quadrature of SPEC §10 written again in numpy) — whatever the integrator does to get there: one of six lights chosen,
+    area sampling, the solid-angle pdf, the MIS weights of both strategies, emitter hits of the BSDF-sampled ray.  An emitter seen directly
+    is exactly Le.  (SPEC §10 has no pure-Lambert configuration, so 'albedo 1 => radiance 1' is not available: see tests/kat_scenes.py.)"""
+    import kat_scenes as K
+    Le = 2.0
+    desc = K.light_box_furnace(base, rough, metal, radiance=Le)
+    sc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+    eye = np.array([0.9, 1.3, 2.2])
+    view = T.look(eye, -eye)
+    got, err = _pixel_batches(sc, view, 0.02, 3, batches=8, frames=500)
+    want = Le * K.directional_albedo(base, rough, metal, eye)
+    assert np.all(np.abs(got - want) < np.maximum(4.0 * err, 0.004 * want)), (got, want, err)
+    assert np.all(want < Le) and np.all(want > 0.3 * Le * min(base))      # below the white furnace: the lobe is single scattering
+    wall = sc.render(8, 8, T.look((0.0, 2.0, 0.0), (0.3, 1.0, 0.2)), 0.5, 3, frames=2)   # straight at an emitter: exactly Le, every sample
+    assert np.all(wall[..., :3] == 2 * Le) and np.all(wall[..., 3] == 2.0)
+
+
+def test_a_closed_box_is_light_tight():
+    """inside a closed box of surfaces (shared edges and corners, three materials) with no light in it, under an environment of radiance
+    100, every sample of every pixel is exactly 0: nothing leaks through an edge, a corner or an offset origin (SPEC §7)"""
+    import kat_scenes as K
+    desc = K.closed_box()
+    sc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+    for eye, d in (((0.3, -0.2, 0.1), (1.0, 0.2, 0.3)), ((-1.9, 1.9, 1.9), (1.0, -1.0, -1.0)), ((0.0, 0.0, 0.0), (-1.0, -1.0, -1.0))):   # the last two: into a corner
+        acc, cnt = sc.render(96, 96, T.look(eye, d), 1.2, 8, frames=3, want_counters=True)
+        assert np.all(acc[..., :3] == 0.0) and np.all(acc[..., 3] == 3.0)
+        assert cnt.closest > 96 * 96 * 3 * 4      # the paths do bounce around in there
+    outside = sc.render(4, 4, T.look((0.0, 0.0, 9.0), (0.0, 0.0, 1.0)), 0.3, 2, frames=1)   # from outside, looking away: the sky is there
+    assert np.all(outside[..., :3] == 100.0)
+
+
+def test_small_light_closed_form():
+    """a 2 cm emitter 2 m above a quad is a point light: L = f(V, L) cos(theta) Le A cos(theta_l) / d^2 (the emitter's extent changes the
+    integrand by (size / d)^2 ~ 1e-4)"""
+    import kat_scenes as K
+    base, rough, metal = (0.7, 0.5, 0.3), 0.6, 0.0
+    desc = K.small_light(base, rough, metal)
+    sc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+    eye, P = np.array([0.0, 1.0, 3.0]), np.array([0.2, 0.0, 0.3])
+    got, err = _pixel_batches(sc, T.look(eye, P - eye), 0.004, 2, batches=4, frames=300)
+    Lp = np.array(desc["light_pos"])
+    w = Lp - P
+    d2 = float(w @ w)
+    wi = w / np.sqrt(d2)
+    V = (eye - P) / np.linalg.norm(eye - P)
+    N = np.array([0.0, 1.0, 0.0])
+    f = K.bsdf(base, rough, metal, N[None], V[None], wi[None])[0]
+    want = f * wi[1] * 4.0e4 * desc["light_area"] * wi[1] / d2       # cos(theta_l) = wi.y: the emitter faces down
+    assert np.all(np.abs(got - want) < np.maximum(4.0 * err, 0.004 * want)), (got, want, err)
