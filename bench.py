@@ -79,6 +79,7 @@ def parse_args(argv=None):
                     "rank 0 also unpacks, resolves and reads back the frame, so it gets fewer tiles; 0 = calibrate in the warm-up, 8 = equal shares")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: path_rays, "
                     "path_waves_per_cu, path_refill, pipe_rays, packet_primary, merge_trace, refill, trace_waves_per_cu, shade_blocks_per_cu, wavefront_rays); every value gives the same frame")
+    ap.add_argument("--sort", type=int, default=0, help="experiments: lpt_renderer_set_sort_queues(flag) on every renderer (1 | 2: outgoing queues by octant, 4: the shading input regrouped in-block)")
     ap.add_argument("--no-shard-emulation", action="store_true", help="skip the shard_emulation leg (rank 0's 1/2, 1/4, 1/8 tile shard of the frame on this GPU)")
     ap.add_argument("--blit-mode", choices=["pathtrace", "temporal", "denoised"], default="pathtrace",
                     help="BlitMode of every renderer (renderer.rs:160-167).  temporal / denoised: every raytrace() is a frame of the ASVGF pipeline (BASELINE config 5's form) — "
@@ -384,6 +385,8 @@ def run(args):
         rr.set_vfov(T.VFOV)
         if blit_mode != lp.BlitMode.Pahtrace:
             rr.set_blit_mode(blit_mode)
+        if args.sort:
+            rr.set_sort_queues(args.sort)
         if comm is not None:
             rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)

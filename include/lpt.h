@@ -500,8 +500,10 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes);
  * full pixel grid unsorted, renderer.rs:484-509).  flag != 0: the shading pass writes the next-bounce and the shadow-ray
  * queue ordered by direction octant inside every 256-ray block (ballot + popcount per key, LDS prefix sum, still one
  * atomic per block), so a traversal wave's 64 rays share one or two octants.  Results are keyed by pixel slot and do
- * not change by a bit; only traversal coherence does.  flag: 1 = next-bounce queue only, 2 = shadow queue only, 3 (or any
- * other non-zero value) = both.  Default: off (measured slower on the bench scene). */
+ * not change by a bit; only traversal coherence does.  flag bits: 1 = next-bounce queue, 2 = shadow queue, 4 = the shading
+ * pass's INPUT: the 256 hits of a block are dealt to its threads by kind (surface / emitter / miss), so that a wave runs one
+ * branch of the shading code with all its lanes (an in-block regroup: LDS only, no extra global traffic); any other non-zero
+ * value = both queues.  Default: off (each measured slower or neutral on the bench scene). */
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
 /* new (no reference knob; SURVEY §5 "Config / flags: no"): launch tuning for experiments and for the tests that compare the kernel
  * variants.  EVERY value gives the same frame bit for bit — only which kernels run, and the size of their grids, changes.  The

@@ -1379,7 +1379,8 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes) {
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_sort_queues: null");
     FLUSH_OR_RETURN(r);
-    r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;   // 1: next-bounce queue, 2: shadow queue, 3 (or any other non-zero): both
+    // 1: next-bounce queue, 2: shadow queue, 4: the shading INPUT regrouped by kind inside each block; any other non-zero value: both queues
+    r->sort_queues = flag ? ((flag & 7) ? (flag & 7) : 3) : 0;
     return LPT_OK;
 }
 // Launch tuning that experiments and the variant tests switch (the reference has no counterpart: SURVEY §5 "Config / flags: no").
@@ -1683,9 +1684,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             }
             stage_begin(r, ST_SHADE, s);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
-                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+                hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+            else if (r->sort_queues & 4)   // the shading input regrouped by kind inside each block (lpt_renderer_set_sort_queues bit 4)
+                hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
             else
-                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+                hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
             stage_end(r, s);
             if (r->merge_trace) {
                 trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);

@@ -16,7 +16,8 @@ def _render(device, sg, pr, view, w, h, bounces, frames, sort, noise=None):
     r.resize(device, sg, pr, (w, h))
     r.set_max_bounces(bounces)
     r.set_vfov(T.VFOV)
-    r.set_sort_queues(3 if sort else 0)
+    r.set_sort_queues(int(sort) if sort is not True else 3)
+    r.set_option("path_rays", 0)      # the sorted stages belong to the per-bounce launches (k_shade); the path kernel has no queues to sort
     r.reset_accumulation()
     r.accumulate = True
     r.reset_ray_counts()
@@ -37,9 +38,10 @@ def test_sorted_queues_do_not_change_a_bit_cornell(device, cornell_glb):
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     for (w, h, b, f) in [(256, 256, 4, 1), (203, 117, 8, 3), (64, 48, 17, 2)]:
         a = _render(device, sg, pr, view, w, h, b, f, False)
-        s = _render(device, sg, pr, view, w, h, b, f, True)
-        assert a[0].tobytes() == s[0].tobytes()
-        assert a[1:] == s[1:]
+        for flag in (True, 4, 7):     # both outgoing queues by octant; the shading INPUT regrouped by kind inside each block; all three
+            s = _render(device, sg, pr, view, w, h, b, f, flag)
+            assert a[0].tobytes() == s[0].tobytes(), flag
+            assert a[1:] == s[1:], flag
     ref, oc = harness.render_oracle(cornell_glb, 256, 256, 4, 1)
     s = _render(device, sg, pr, view, 256, 256, 4, 1, True)
     assert s[0].tobytes() == ref.tobytes()
@@ -54,9 +56,10 @@ def test_sorted_queues_atrium_textured(device):
     pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
     a = _render(device, sg, pr, view, 480, 270, 8, 2, False)
-    s = _render(device, sg, pr, view, 480, 270, 8, 2, True)
-    assert a[0].tobytes() == s[0].tobytes()
-    assert a[1:] == s[1:]
+    for flag in (True, 4):
+        s = _render(device, sg, pr, view, 480, 270, 8, 2, flag)
+        assert a[0].tobytes() == s[0].tobytes(), flag
+        assert a[1:] == s[1:], flag
     pr.close()
     sg.close()
 
