@@ -529,6 +529,7 @@ def run(args):
     span_frame()
     fence([r])
     st = r.ray_counts()
+    r_occ_cell = r.get_option("occ_cell_milli")
     r.enable_stats(False)
     # bounce 0 is traced by packet traversal (k_trace_packet: one tree walk per 64 coherent rays) — another kernel, with its own
     # counters; `nodes` / `tris` are k_trace's, per closest-hit ray of the bounces it traces
@@ -773,6 +774,11 @@ def run(args):
                          "from_profiles": profiles_j,
                          "rays_per_launch": rays_per_launch, "bytes_per_ray": b_ray, "bytes_per_shadow_ray": b_sh, "nodes_per_ray": n_bar, "tris_per_ray": t_bar,
                          "shadow_nodes_per_ray": ns_bar, "shadow_tris_per_ray": ts_bar,
+                         "occluder_cache_probe": {"what": "stats kernels only: what a table of the last occluding triangle per %.2f-unit cell of the shadow rays' origins would have answered "
+                                                          "(found = an entry was there, hits = its triangle occludes the ray); no kernel uses such a cache" % (r_occ_cell * 1e-3),
+                                                  "shadow_rays": st.shadow, "occluded": st.shadow_occluded, "found": st.occluder_cache_found, "hits": st.occluder_cache_hits,
+                                                  "occluded_frac": st.shadow_occluded / max(st.shadow, 1), "hit_frac_of_shadow_rays": st.occluder_cache_hits / max(st.shadow, 1),
+                                                  "hit_frac_of_occluded": st.occluder_cache_hits / max(st.shadow_occluded, 1)},
                          "wave": {"live_lanes_per_step": st.live_lanes / max(st.wave_steps, 1), "node_lanes_per_step": st.node_lanes / max(st.wave_steps, 1),
                                   "tri_lanes_per_step": st.tri_lanes / max(st.wave_steps, 1), "lane_slots_per_ray": 64.0 * st.wave_steps / max(kt_closest, 1)},
                          "packet": packet_j},

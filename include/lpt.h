@@ -148,6 +148,13 @@ typedef struct lpt_ray_counts {
     uint64_t primary;      /* closest-hit rays traced as packets                               */
     uint64_t packet_nodes; /* nodes entered, once per PACKET (stats enabled only)              */
     uint64_t packet_tris;  /* triangles fetched, once per PACKET (stats enabled only)          */
+    /* ABI 5, stats enabled only, per-bounce launches only: the shadow rays that found an occluder, and the occluder-cache PROBE — what a
+     * table of the last occluding triangle per cell of a grid over the shadow rays' origins (LPT_OPT_OCC_CELL_MILLI) would have answered
+     * at each ray's start: entries found, and entries whose triangle occludes the ray (a hit would end that ray after one triangle test).
+     * A measurement; no kernel uses such a cache. */
+    uint64_t shadow_occluded;
+    uint64_t occluder_cache_found;
+    uint64_t occluder_cache_hits;
 } lpt_ray_counts;
 
 typedef struct lpt_timing {
@@ -521,7 +528,8 @@ typedef enum lpt_option {
                                      * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 800 000, the
                                      * measured cross-over; 0: never */
     LPT_OPT_PATH_WAVES_PER_CU = 9,  /* path kernel: persistent waves per CU (default 16) */
-    LPT_OPT_PATH_REFILL = 10        /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
+    LPT_OPT_PATH_REFILL = 10,       /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
+    LPT_OPT_OCC_CELL_MILLI = 11     /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

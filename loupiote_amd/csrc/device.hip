@@ -164,6 +164,7 @@ struct Wavefront {
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
+constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 800000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
@@ -228,6 +229,8 @@ struct lpt_renderer {
     hipEvent_t xevent = nullptr;
     bool xevent_recorded = false;
     Totals *totals = nullptr;
+    uint32_t *occ_table = nullptr;   // occluder-cache probe (stats only): kOccEntries leaf slots + 1, zero = empty; allocated by enable_stats
+    float occ_cell = 0.25f;          // its grid cell (scene units); LPT_OPT_OCC_CELL_MILLI
     void *default_probe = nullptr;
     float *srgb_thr = nullptr;   // 256 floats: the linear value at which sRGB code i starts (k_tonemap, SPEC §13.2)
     void *noise = nullptr;
@@ -1214,6 +1217,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
         if (wf.ctr) hipFree(wf.ctr);
     }
     if (r->totals) hipFree(r->totals);
+    if (r->occ_table) hipFree(r->occ_table);
     if (r->d_table) hipFree(r->d_table);
     if (r->default_probe) hipFree(r->default_probe);
     if (r->srgb_thr) hipFree(r->srgb_thr);
@@ -1399,6 +1403,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_PATH_RAYS: r->path_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_PATH_WAVES_PER_CU: if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
     case LPT_OPT_PATH_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
+    case LPT_OPT_OCC_CELL_MILLI: r->occ_cell = (float)std::min<uint64_t>(value, 1000000u) * 1.0e-3f; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1416,6 +1421,7 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_PATH_RAYS: *value = r->path_rays; break;
     case LPT_OPT_PATH_WAVES_PER_CU: *value = r->path_waves_per_cu; break;
     case LPT_OPT_PATH_REFILL: *value = (uint64_t)r->path_refill; break;
+    case LPT_OPT_OCC_CELL_MILLI: *value = (uint64_t)(r->occ_cell * 1000.0f + 0.5f); break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1424,6 +1430,12 @@ int lpt_renderer_enable_stats(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_enable_stats: null");
     FLUSH_OR_RETURN(r);
     r->stats = flag != 0;
+    if (flag) {   // the occluder-cache probe's table (kernels.h OccProbe): empty at the start of every stats session
+        HIP_TRY(hipSetDevice(r->dev->ordinal));
+        if (!r->occ_table) HIP_TRY(hipMalloc(&r->occ_table, sizeof(uint32_t) * kOccEntries));
+        HIP_TRY(hipMemsetAsync(r->occ_table, 0, sizeof(uint32_t) * kOccEntries, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
     return LPT_OK;
 }
 int lpt_renderer_enable_timings(lpt_renderer *r, int flag) {
@@ -1638,14 +1650,17 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
         // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
         // instead of 2*nb; split (LPT_MERGE_TRACE=0): IntersectorPass and the shadow pass as separate launches.
+        // the occluder-cache probe rides with the stats kernels only (kernels.h OccProbe); its table belongs to the renderer
+        OccProbe occ{nullptr, 0u, 0.0f};
+        if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
             if (pipe) {
-                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
-                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
-            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill);
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
+                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
             stage_end(r, s);
         };
         if (r->merge_trace) {
@@ -2041,6 +2056,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
     out->wave_steps = t.wave_steps; out->live_lanes = t.live_lanes; out->node_lanes = t.node_lanes; out->tri_lanes = t.tri_lanes;
     out->primary = t.primary; out->packet_nodes = t.packet_nodes; out->packet_tris = t.packet_tris;
+    out->shadow_occluded = t.shadow_occluded; out->occluder_cache_found = t.occ_found; out->occluder_cache_hits = t.occ_hits;
     return LPT_OK;
 }
 

@@ -76,9 +76,12 @@ struct FrameCounters {
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
     unsigned long long wave_steps, live_lanes, node_lanes, tri_lanes;  // closest-hit kernel, stats only
     unsigned long long packet_nodes, packet_tris;   // k_trace_packet, stats only: nodes entered / triangles tested per PACKET, summed
+    // stats only: the shadow rays that found an occluder, and the occluder-cache PROBE (k_trace<STATS>: what a cache of the last occluding
+    // triangle per origin cell would have answered — entries found, entries whose triangle occludes the new ray; the traversal is not changed)
+    unsigned long long shadow_occluded, occ_found, occ_hits;
 };
 struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes,
-                                   primary, packet_nodes, packet_tris; };   // mirrors lpt_ray_counts
+                                   primary, packet_nodes, packet_tris, shadow_occluded, occ_found, occ_hits; };   // mirrors lpt_ray_counts
 
 // Tile ownership.  Tile t (row-major over the tile grid) belongs to VIRTUAL rank t % V; the V virtual ranks are dealt to
 // the ranks in proportion to their weights (a rank that also assembles, reads back or filters the frame gets fewer tiles).  With
@@ -477,6 +480,7 @@ __device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, ui
         if (ray_triangle(r0, r1, r2, rs.o, rs.d, rs.best.t, t, u, v)) {
             const uint32_t prim = sc.leaf_prim[ti];
             if (t < rs.best.t || prim < rs.best.prim) { rs.best.t = t; rs.best.u = u; rs.best.v = v; rs.best.prim = prim; }
+            if (STATS && ANY) rs.best.v = __uint_as_float(ti);   // the occluder's leaf slot, for the occluder-cache probe (an any-hit ray's v is not read)
             if (ANY) return true;
         }
     }
@@ -664,6 +668,15 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue s
     }
 }
 
+// Occluder-cache PROBE (STATS variants only): a table of the last occluding triangle per cell of a grid over the shadow
+// rays' origins.  The probe asks, for every finished shadow ray, what the cache would have answered at its start — is there an entry,
+// does that triangle occlude this ray (Woop test) — and then records the ray's own occluder.  Nothing about the traversal changes.
+struct OccProbe { uint32_t *table; uint32_t mask; float inv_cell; };
+__device__ __forceinline__ uint32_t occ_key(const OccProbe &oc, f3 o) {
+    const int x = (int)floorf(o.x * oc.inv_cell), y = (int)floorf(o.y * oc.inv_cell), z = (int)floorf(o.z * oc.inv_cell);
+    return pcg_hash((uint32_t)x * 73856093u ^ (uint32_t)y * 19349663u ^ (uint32_t)z * 83492791u) & oc.mask;
+}
+
 // Closest-hit rays of bounce `cb` and shadow rays of bounce `sb` in ONE persistent launch (either may be
 // absent: -1).  Both queues were filled by the same shading pass; tracing them together halves the number of
 // traversal launches per frame and lets the short shadow rays fill the lanes that the tail of the closest-hit
@@ -673,7 +686,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue s
 // PIPE: ray_step_pipe (one memory round trip per step) instead of ray_step_any — same results, for launches of few rays.
 template <bool STATS, bool PIPE = false>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
-                                                       int cb, int sb, int refill) {
+                                                       int cb, int sb, int refill, OccProbe occ) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pc, ps;
     puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : ctr->qcount[cb]);
@@ -683,6 +696,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
+    uint32_t n_occluded = 0, n_found = 0, n_would = 0;        // occluder-cache probe (STATS)
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
@@ -694,6 +708,19 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             // the stores run for a batch of lanes instead of once per finishing lane
             if (finished) {
                 if (shadow) {
+                    if (STATS && occ.table) {
+                        const uint32_t key = occ_key(occ, rs.o);
+                        const uint32_t cached = occ.table[key];
+                        const bool occluded = rs.best.prim != 0xFFFFFFFFu;
+                        bool would_hit = false;
+                        if (cached) {
+                            const float4 *w = sc.woop + 3u * (size_t)(cached - 1u);
+                            float t, u, v;
+                            would_hit = ray_triangle(w[0], w[1], w[2], rs.o, rs.d, sq.o[ray].w, t, u, v);
+                        }
+                        if (occluded) occ.table[key] = __float_as_uint(rs.best.v) + 1u;
+                        n_occluded += occluded ? 1u : 0u; n_found += cached ? 1u : 0u; n_would += would_hit ? 1u : 0u;
+                    }
                     if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
                         const uint32_t slot = __float_as_uint(rs.best.u);   // the pixel slot rides in the unused `u` of an any-hit ray
                         const float4 c = sq.c[ray];
@@ -746,6 +773,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
         atomicAdd(&ctr->tris, (unsigned long long)n_tris);
         atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
         atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
+        if (occ.table) {
+            atomicAdd(&ctr->shadow_occluded, (unsigned long long)n_occluded);
+            atomicAdd(&ctr->occ_found, (unsigned long long)n_found);
+            atomicAdd(&ctr->occ_hits, (unsigned long long)n_would);
+        }
         if (lane == 0) {
             atomicAdd(&ctr->wave_steps, (unsigned long long)w_steps);
             atomicAdd(&ctr->live_lanes, (unsigned long long)w_live);
@@ -1727,6 +1759,7 @@ __global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
+    tot->shadow_occluded += ctr->shadow_occluded; tot->occ_found += ctr->occ_found; tot->occ_hits += ctr->occ_hits;
 }
 
 // mean radiance (a = 1 where sampled) and sRGB8 (SPEC §13.2)
