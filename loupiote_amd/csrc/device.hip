@@ -166,6 +166,7 @@ struct Wavefront {
 constexpr int kMaxLanes = 4;
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 800000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over
+constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
 struct lpt_renderer {
@@ -1791,9 +1792,12 @@ static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
     const uint32_t granule = whole_rows ? tiles_x * area : area;  // slots per tile row / per tile
     const uint32_t granules = granule ? n_slots / granule : 0u;
     uint32_t per_piece = granules;
-    if (!r->max_fused && r->mode == LPT_BLIT_PATHTRACE && granules > 1u && (uint64_t)n_slots * b.n > r->wavefront_rays) {
+    // ... and a batch of more than 3 M rays that would still fit one wavefront leaves as TWO (on the renderer's two lanes): a 1/2 shard of the headline frame
+    // (4.15 M rays) 7.22 -> 6.81 ms; below that the halves are too small to hide each other's drains (a 1/4 shard, 2 x 1.04 M: 4.62 -> 4.75 ms; profiles/r04_experiments_ab.txt E)
+    const uint64_t total = (uint64_t)n_slots * b.n;
+    if (!r->max_fused && r->mode == LPT_BLIT_PATHTRACE && granules > 1u && (total > r->wavefront_rays || (total > kSplitRays && r->wavefront_rays >= kSplitRays && r->n_lanes > 1))) {
         const uint64_t fit = r->wavefront_rays / ((uint64_t)granule * b.n);           // granules of b.n samples in about 4 M rays
-        const uint32_t pieces = div_up(granules, (uint32_t)std::max<uint64_t>(fit, 1u));
+        const uint32_t pieces = std::max(2u, div_up(granules, (uint32_t)std::max<uint64_t>(fit, 1u)));
         per_piece = div_up(granules, pieces);                     // the same number of pieces, evened out
     }
     Ticket tk[kMaxLanes];
