@@ -547,6 +547,9 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
  * emitted by bounce b; up to `cap` entries each (either pointer may be NULL).  Blocking. */
 int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *shadow, uint32_t cap);
 int lpt_renderer_reset_ray_counts(lpt_renderer *r);
+/* new, stats enabled only: traversal steps per ray over the per-bounce traversal launches of the LAST wavefront — the maximum (the longest
+ * ray of a launch sets its duration) and a histogram by power of two (hist12[k]: 2^k <= steps < 2^(k+1)).  Blocking. */
+int lpt_renderer_get_step_histogram(lpt_renderer *r, uint32_t *max_steps, uint32_t *hist12);
 /* count BVH nodes visited / triangles tested per ray (slower kernel variant) */
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag);
 int lpt_renderer_synchronize(lpt_renderer *r);

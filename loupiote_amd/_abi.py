@@ -162,6 +162,7 @@ SIGNATURES = {
     "lpt_renderer_get_queue_counts": (_i, [_vp, _vp, _vp, _u32]),
     "lpt_renderer_get_ray_counts": (_i, [_vp, C.POINTER(RayCounts)]),
     "lpt_renderer_reset_ray_counts": (_i, [_vp]),
+    "lpt_renderer_get_step_histogram": (_i, [_vp, _pu32, _vp]),
     "lpt_renderer_enable_stats": (_i, [_vp, _i]),
     "lpt_renderer_synchronize": (_i, [_vp]),
     "lpt_renderer_stream": (_i, [_vp, _pvp]),

@@ -490,6 +490,13 @@ class Renderer:
         _check(A.lib().lpt_renderer_get_option(self._h, A.OPTIONS[name] if isinstance(name, str) else int(name), C.byref(v)))
         return v.value
 
+    def step_histogram(self):
+        """stats kernels only: (longest ray in traversal steps, histogram by power of two) of the last wavefront's per-bounce traversal launches"""
+        mx = C.c_uint32()
+        h = np.zeros(12, np.uint32)
+        _check(A.lib().lpt_renderer_get_step_histogram(self._h, C.byref(mx), A.ptr(h)))
+        return mx.value, h
+
     def queue_counts(self, n=64):
         """per-bounce (closest-hit, shadow) queue sizes of the last traced frame"""
         c, s = np.zeros(n, np.uint32), np.zeros(n, np.uint32)

@@ -2104,6 +2104,21 @@ int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *
     return LPT_OK;
 }
 
+// stats kernels only: traversal steps per ray over the per-bounce traversal launches of the LAST wavefront (its longest ray sets a launch's duration)
+int lpt_renderer_get_step_histogram(lpt_renderer *r, uint32_t *max_steps, uint32_t *hist12) {
+    if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_step_histogram: null");
+    FLUSH_OR_RETURN(r);
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    const FrameCounters *ctr = r->wf[r->last_lane].ctr;
+    if (max_steps) *max_steps = 0;
+    if (hist12) memset(hist12, 0, sizeof(uint32_t) * 12);
+    if (!ctr) return LPT_OK;
+    if (max_steps) HIP_TRY(hipMemcpy(max_steps, &ctr->max_steps, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (hist12) HIP_TRY(hipMemcpy(hist12, ctr->step_hist, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost));
+    return LPT_OK;
+}
+
 // ============================================================================ multi-GPU frame exchange
 int lpt_comm_unique_id(void *out_id) {
     if (!out_id) return fail(LPT_ERR_INVALID_ARG, "lpt_comm_unique_id: null");

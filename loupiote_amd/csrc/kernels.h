@@ -79,6 +79,10 @@ struct FrameCounters {
     // stats only: the shadow rays that found an occluder, and the occluder-cache PROBE (k_trace<STATS>: what a cache of the last occluding
     // triangle per origin cell would have answered — entries found, entries whose triangle occludes the new ray; the traversal is not changed)
     unsigned long long shadow_occluded, occ_found, occ_hits;
+    // stats only: traversal steps of a ray in k_trace — the longest one of the launch sets its duration —: maximum and a histogram by
+    // power of two (bucket k: 2^k <= steps < 2^(k+1), k = 0..11)
+    uint32_t max_steps;
+    uint32_t step_hist[12];
 };
 struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes,
                                    primary, packet_nodes, packet_tris, shadow_occluded, occ_found, occ_hits; };   // mirrors lpt_ray_counts
@@ -697,6 +701,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
     uint32_t n_occluded = 0, n_found = 0, n_would = 0;        // occluder-cache probe (STATS)
+    uint32_t my_steps = 0;                                    // traversal steps of the ray in hand (STATS)
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
@@ -707,6 +712,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             // results are written here, together with the refill, so that the emitter test / the deposit and
             // the stores run for a batch of lanes instead of once per finishing lane
             if (finished) {
+                if (STATS) {
+                    atomicMax(&ctr->max_steps, my_steps);
+                    atomicAdd(&ctr->step_hist[min(11, 31 - __clz((int)max(my_steps, 1u)))], 1u);
+                    my_steps = 0;
+                }
                 if (shadow) {
                     if (STATS && occ.table) {
                         const uint32_t key = occ_key(occ, rs.o);
@@ -759,6 +769,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             w_live += (uint32_t)__popcll(__ballot(active));
             w_node += (uint32_t)__popcll(__ballot(PIPE ? active && rs.tg2.y == 0u && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0) : active && rs.tg.y == 0u));
         }
+        if (STATS && active) my_steps++;
         if (active && (PIPE ? ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt) : ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt))) {
             active = false;
             finished = true;
