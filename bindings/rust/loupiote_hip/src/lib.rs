@@ -1,0 +1,236 @@
+//! Safe layer over `libloupiote_hip.so` with the names and the call shapes of the reference's `crates/lib`
+//! (`Device`, `Scene`, `SceneGPU`, `ProbeGPU`, `Renderer`, `BlitMode`, `Error`, `loaders::load_gltf`;
+//! reference `crates/lib/src/lib.rs:1-11`).  The wgpu parameters of the reference's signatures (`&wgpu::Device`, `&wgpu::Queue`,
+//! `&mut wgpu::CommandEncoder`) have no meaning on a compute-only part and are dropped here; INTEGRATION.md §3 shows the
+//! adapters that keep them for `crates/standalone`.  Not compiled in the development image (no Rust toolchain): the `ffi` module
+//! is generated from `include/lpt.h` (`tools/gen_rust_ffi.py`), this file is written against it by hand.
+pub mod ffi;
+
+use std::ffi::CStr;
+use std::ptr;
+
+/// reference `crates/lib/src/errors.rs:2-6` (+ the ABI's own codes)
+#[derive(Debug)]
+pub enum Error {
+    FileNotFound(String),
+    TextureToBufferReadFail,
+    AccelBuild(String),
+    Hip(String),
+    Rccl(String),
+    InvalidArg(String),
+}
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(ffi::lpt_last_error()).to_string_lossy().into_owned() }
+}
+
+fn check(status: i32) -> Result<(), Error> {
+    match status {
+        ffi::LPT_OK => Ok(()),
+        ffi::LPT_ERR_FILE_NOT_FOUND => Err(Error::FileNotFound(last_error())),
+        ffi::LPT_ERR_READBACK => Err(Error::TextureToBufferReadFail),
+        ffi::LPT_ERR_ACCEL_BUILD => Err(Error::AccelBuild(last_error())),
+        ffi::LPT_ERR_HIP => Err(Error::Hip(last_error())),
+        ffi::LPT_ERR_RCCL => Err(Error::Rccl(last_error())),
+        _ => Err(Error::InvalidArg(last_error())),
+    }
+}
+
+/// reference `crates/lib/src/device.rs:80` `Device::new`: one GPU
+pub struct Device { h: *mut ffi::lpt_device }
+impl Device {
+    pub fn new(hip_ordinal: i32) -> Result<Self, Error> {
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_device_create(hip_ordinal, &mut h) })?;
+        Ok(Self { h })
+    }
+    pub fn synchronize(&self) -> Result<(), Error> { check(unsafe { ffi::lpt_device_synchronize(self.h) }) }
+}
+impl Drop for Device { fn drop(&mut self) { unsafe { ffi::lpt_device_destroy(self.h); } } }
+
+/// reference `crates/lib/src/scene.rs:30-54` `Scene` (`Scene::default()` seeds one dummy element per array)
+pub struct Scene { h: *mut ffi::lpt_scene }
+impl Default for Scene {
+    fn default() -> Self {
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_scene_create(&mut h) }).expect("lpt_scene_create");
+        Self { h }
+    }
+}
+impl Scene {
+    /// `BLASArray::add_bvh_indexed` (reference `loaders/gltf.rs:97-105`): positions are `[f32; 4]`, normals `[f32; 3]`, uvs `[f32; 2]`
+    pub fn add_mesh(&mut self, positions: &[[f32; 4]], normals: Option<&[[f32; 3]]>, uvs: Option<&[[f32; 2]]>, indices: Option<&[u32]>) -> Result<u32, Error> {
+        let mut out = 0u32;
+        let n = positions.len() as u32;
+        check(unsafe {
+            ffi::lpt_scene_add_mesh(self.h, positions.as_ptr() as *const _, 16,
+                                    normals.map_or(ptr::null(), |x| x.as_ptr() as *const _), 12,
+                                    uvs.map_or(ptr::null(), |x| x.as_ptr() as *const _), 8, n,
+                                    indices.map_or(ptr::null(), |x| x.as_ptr()), indices.map_or(0, |x| x.len() as u32), &mut out)
+        })?;
+        Ok(out)
+    }
+    /// `add_instance(blas, transform, material)` (reference `loaders/gltf.rs:141-145`); column-major `glam::Mat4::to_cols_array()`
+    pub fn add_instance(&mut self, blas_index: u32, model_to_world: &[f32; 16], material_index: u32) -> Result<u32, Error> {
+        let mut out = 0u32;
+        check(unsafe { ffi::lpt_scene_add_instance(self.h, blas_index, model_to_world.as_ptr(), material_index, &mut out) })?;
+        Ok(out)
+    }
+    /// `Instance::set_transform` (reference `crates/standalone/src/lib.rs:118-121`)
+    pub fn set_instance_transform(&mut self, index: u32, model_to_world: &[f32; 16]) -> Result<(), Error> {
+        check(unsafe { ffi::lpt_scene_set_instance_transform(self.h, index, model_to_world.as_ptr()) })
+    }
+    pub fn add_material(&mut self, material: &ffi::lpt_material) -> Result<u32, Error> {
+        let mut out = 0u32;
+        check(unsafe { ffi::lpt_scene_add_material(self.h, material, &mut out) })?;
+        Ok(out)
+    }
+    pub fn add_image(&mut self, rgba8: &[u8], width: u32, height: u32) -> Result<u32, Error> {
+        assert!(rgba8.len() >= (width as usize) * (height as usize) * 4);
+        let mut out = 0u32;
+        check(unsafe { ffi::lpt_scene_add_image(self.h, rgba8.as_ptr(), width, height, &mut out) })?;
+        Ok(out)
+    }
+}
+impl Drop for Scene { fn drop(&mut self) { unsafe { ffi::lpt_scene_destroy(self.h); } } }
+
+pub mod loaders {
+    use super::{check, ffi, Error, Scene};
+    /// reference `crates/lib/src/loaders/gltf.rs:46`: appends to `scene`
+    pub fn load_gltf(data: &[u8], scene: &mut Scene) -> Result<(), Error> {
+        check(unsafe { ffi::lpt_load_gltf(scene.h, data.as_ptr(), data.len()) })
+    }
+}
+
+/// reference `crates/lib/src/scene.rs:151` `SceneGPU::new_from_scene` (the CPU scene stays with the caller)
+pub struct SceneGPU { h: *mut ffi::lpt_scene_gpu }
+impl SceneGPU {
+    pub fn new_from_scene(scene: &Scene, device: &Device) -> Result<Self, Error> {
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_scene_upload(device.h, scene.h, &mut h) })?;
+        Ok(Self { h })
+    }
+    /// after `Scene::set_instance_transform`: re-bake the moved instances and refit the tree on the GPU
+    pub fn update_instances(&mut self, scene: &Scene) -> Result<u32, Error> {
+        let mut n = 0u32;
+        check(unsafe { ffi::lpt_scene_gpu_update_instances(self.h, scene.h, &mut n) })?;
+        Ok(n)
+    }
+}
+impl Drop for SceneGPU { fn drop(&mut self) { unsafe { ffi::lpt_scene_gpu_destroy(self.h); } } }
+
+/// reference `crates/lib/src/scene.rs:72` `ProbeGPU::new`: RGBE8, equirectangular
+pub struct ProbeGPU { h: *mut ffi::lpt_probe }
+impl ProbeGPU {
+    pub fn new(device: &Device, rgbe8: &[u8], width: u32, height: u32) -> Result<Self, Error> {
+        assert!(rgbe8.len() >= (width as usize) * (height as usize) * 4);
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_probe_upload(device.h, rgbe8.as_ptr(), width, height, &mut h) })?;
+        Ok(Self { h })
+    }
+}
+impl Drop for ProbeGPU { fn drop(&mut self) { unsafe { ffi::lpt_probe_destroy(self.h); } } }
+
+/// reference `crates/lib/src/renderer.rs:160-167` (the spelling `Pahtrace` is the reference's)
+#[derive(Copy, Clone, Debug, PartialEq, Eq)]
+#[repr(i32)]
+pub enum BlitMode { Pahtrace = 0, DenoisedPathrace = 1, Temporal = 2, GBuffer = 3, MotionVector = 4 }
+
+/// reference `crates/lib/src/renderer.rs:169-811`
+pub struct Renderer {
+    h: *mut ffi::lpt_renderer,
+    /// pub field of the reference (`renderer.rs:203`); applied by `resize`
+    pub downsample_factor: f32,
+    /// pub field of the reference (`renderer.rs:204`); handed to the library by `raytrace`
+    pub accumulate: bool,
+    size: (u32, u32),
+}
+impl Renderer {
+    /// `renderer.rs:209`
+    pub fn max_ssbo_element_in_bytes() -> u32 { unsafe { ffi::lpt_max_per_pixel_bytes() } }
+    /// `renderer.rs:220` (the swapchain format has no meaning here)
+    pub fn new(device: &Device, original_size: (u32, u32)) -> Result<Self, Error> {
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_renderer_create(device.h, original_size.0, original_size.1, &mut h) })?;
+        let mut r = Self { h, downsample_factor: 0.5, accumulate: false, size: (0, 0) };
+        unsafe { ffi::lpt_renderer_get_size(r.h, &mut r.size.0, &mut r.size.1); }
+        Ok(r)
+    }
+    /// `renderer.rs:326`
+    pub fn resize(&mut self, scene: &SceneGPU, probe: Option<&ProbeGPU>, size: (u32, u32)) -> Result<(), Error> {
+        check(unsafe { ffi::lpt_renderer_set_downsample(self.h, self.downsample_factor) })?;
+        check(unsafe { ffi::lpt_renderer_resize(self.h, scene.h, probe.map_or(ptr::null(), |p| p.h as *const _), size.0, size.1) })?;
+        check(unsafe { ffi::lpt_renderer_get_size(self.h, &mut self.size.0, &mut self.size.1) })
+    }
+    /// `renderer.rs:687`
+    pub fn set_resources(&mut self, scene: &SceneGPU, probe: Option<&ProbeGPU>) -> Result<(), Error> {
+        check(unsafe { ffi::lpt_renderer_set_resources(self.h, scene.h, probe.map_or(ptr::null(), |p| p.h as *const _)) })
+    }
+    /// `renderer.rs:392`: RECORDS one sample per pixel from `view_transform` (camera-to-world, column-major); launched by the next
+    /// submission point (`submit`, any read) — INTEGRATION.md §3a
+    pub fn raytrace(&mut self, view_transform: &[f32; 16]) -> Result<(), Error> {
+        check(unsafe { ffi::lpt_renderer_set_accumulate(self.h, self.accumulate as i32) })?;
+        check(unsafe { ffi::lpt_renderer_raytrace(self.h, view_transform.as_ptr()) })
+    }
+    /// the app's `queue.submit(Some(encoder.finish()))` (`crates/standalone/src/app.rs:335-337`)
+    pub fn submit(&mut self) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_submit(self.h) }) }
+    /// `renderer.rs:609`
+    pub fn reset_accumulation(&mut self) -> Result<(), Error> {
+        self.accumulate = false;
+        check(unsafe { ffi::lpt_renderer_reset_accumulation(self.h) })
+    }
+    /// `renderer.rs:620`
+    pub fn upload_noise_texture(&mut self, data: &[u8], width: u32, height: u32, bytes_per_row: u32) -> Result<(), Error> {
+        assert!(data.len() >= (bytes_per_row as usize) * (height as usize));
+        check(unsafe { ffi::lpt_renderer_upload_noise(self.h, data.as_ptr(), width, height, bytes_per_row) })
+    }
+    /// `renderer.rs:666`
+    pub fn use_noise_texture(&mut self, flag: bool) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_use_noise(self.h, flag as i32) }) }
+    /// `renderer.rs:675`
+    pub fn set_blit_mode(&mut self, mode: BlitMode) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_set_blit_mode(self.h, mode as i32) }) }
+    /// `renderer.rs:683`
+    pub fn get_size(&self) -> &(u32, u32) { &self.size }
+    /// `renderer.rs:727`: tight rows of sRGB RGBA8; blocking (the reference awaits `device.poll(Wait)`, `:791`)
+    pub fn read_pixels(&mut self) -> Result<Vec<u8>, Error> {
+        let mut out = vec![0u8; (self.size.0 as usize) * (self.size.1 as usize) * 4];
+        check(unsafe { ffi::lpt_renderer_read_pixels(self.h, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+    /// new: the mean radiance as float RGBA (the parity surface)
+    pub fn read_radiance(&mut self) -> Result<Vec<f32>, Error> {
+        let mut out = vec![0f32; (self.size.0 as usize) * (self.size.1 as usize) * 4];
+        check(unsafe { ffi::lpt_renderer_read_radiance(self.h, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+    /// `renderer.rs:551` without a swapchain: sRGB RGBA8 into the caller's rows
+    pub fn blit_rgba8(&mut self, dst: &mut [u8], row_bytes: usize) -> Result<(), Error> {
+        assert!(row_bytes >= (self.size.0 as usize) * 4 && dst.len() >= row_bytes * (self.size.1 as usize));
+        check(unsafe { ffi::lpt_renderer_blit_rgba8(self.h, dst.as_mut_ptr(), row_bytes) })
+    }
+    /// build-only knobs (the reference's constants: 3 bounces, `renderer.rs:398-399`)
+    pub fn set_max_bounces(&mut self, bounces: u32) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_set_max_bounces(self.h, bounces) }) }
+    pub fn set_seed(&mut self, seed: u32) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_set_seed(self.h, seed) }) }
+    /// launch tuning (the `LPT_OPT_` constants of `ffi`): never changes a frame
+    pub fn set_option(&mut self, option: i32, value: u64) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_set_option(self.h, option, value) }) }
+    /// tile-sharded frames: bind a communicator (implies `set_shard(rank, world, 32, 8)`), then `exchange` after the frame's `raytrace` calls
+    pub fn set_comm(&mut self, comm: &Comm) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_set_comm(self.h, comm.h) }) }
+    pub fn exchange(&mut self, mode: i32) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_exchange(self.h, mode) }) }
+}
+impl Drop for Renderer { fn drop(&mut self) { unsafe { ffi::lpt_renderer_destroy(self.h); } } }
+
+/// one rank of a node-wide frame (new functionality: the reference is single-GPU); RCCL lives inside the library
+pub struct Comm { h: *mut ffi::lpt_comm }
+impl Comm {
+    /// rank 0 creates the id and ships its 128 bytes to the other ranks out of band
+    pub fn unique_id() -> Result<[u8; 128], Error> {
+        let mut id = [0u8; 128];
+        check(unsafe { ffi::lpt_comm_unique_id(id.as_mut_ptr() as *mut _) })?;
+        Ok(id)
+    }
+    pub fn new(device: &Device, unique_id: &[u8; 128], rank: i32, world_size: i32) -> Result<Self, Error> {
+        let mut h = ptr::null_mut();
+        check(unsafe { ffi::lpt_comm_create(device.h, unique_id.as_ptr() as *const _, rank, world_size, &mut h) })?;
+        Ok(Self { h })
+    }
+}
+impl Drop for Comm { fn drop(&mut self) { unsafe { ffi::lpt_comm_destroy(self.h); } } }
