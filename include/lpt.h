@@ -517,7 +517,8 @@ int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
  * library reads no environment variable for any of this (round 3 did; a host's environment must not change which kernels run). */
 typedef enum lpt_option {
     LPT_OPT_MERGE_TRACE = 1,        /* 1 (default): closest-hit rays of bounce b+1 and shadow rays of bounce b in one launch; 0: separate launches */
-    LPT_OPT_PACKET_PRIMARY = 2,     /* 1 (default): bounce 0 by packet traversal, one tree walk per 64 coherent rays; 0: per ray */
+    LPT_OPT_PACKET_PRIMARY = 2,     /* bounce 0 by packet traversal, one tree walk per 8x8-pixel patch: 2 (default) = where the patch is narrow (up to 1.8 mrad
+                                     * per pixel: 1080p, 4K, 1024^2 at 45 degrees; not a 270p preview), 1 = always, 0 = never (per ray) */
     LPT_OPT_PIPE_RAYS = 3,          /* wavefronts of at most this many rays trace with the one-round-trip step (default: all); 0: never */
     LPT_OPT_WAVEFRONT_RAYS = 4,     /* rays per wavefront an automatic submission aims at (default 4 194 304) */
     LPT_OPT_REFILL = 5,             /* per-bounce traversal: lanes live below which a wave refills (default 44) */

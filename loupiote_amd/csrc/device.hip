@@ -164,6 +164,7 @@ struct Wavefront {
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
+constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to this angle per pixel (measured: 1.53 mrad, 960x540: packets 4.46 against 4.51 ms; 2.05 mrad, 720x405: 3.32 against 3.20)
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 800000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts
@@ -192,7 +193,7 @@ struct lpt_renderer {
     struct Pending { float view[16]; uint32_t n = 0, frame_count0 = 1, seed0 = 0; bool acc0 = false; } pend;
     uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
                                // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
-    bool packet_primary = true;    // bounce 0 by packet traversal (k_trace_packet); LPT_OPT_PACKET_PRIMARY 0: per-ray traversal like every other bounce
+    uint32_t packet_primary = 2u;  // bounce 0 by packet traversal (k_trace_packet): 2 = where an 8x8-pixel patch is narrow enough (wavefront_trace), 1 = always, 0 = never (LPT_OPT_PACKET_PRIMARY)
     uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_OPT_PIPE_RAYS 0: none
     uint64_t wavefront_rays = kWavefrontRays;   // LPT_OPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
     // wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (k_path: no chip-wide barrier per
@@ -1395,7 +1396,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     FLUSH_OR_RETURN(r);
     switch (option) {
     case LPT_OPT_MERGE_TRACE: r->merge_trace = value != 0; break;
-    case LPT_OPT_PACKET_PRIMARY: r->packet_primary = value != 0; break;
+    case LPT_OPT_PACKET_PRIMARY: if (value > 2u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PACKET_PRIMARY: 0 (never), 1 (always), 2 (by pixel footprint)"); r->packet_primary = (uint32_t)value; break;
     case LPT_OPT_PIPE_RAYS: r->pipe_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_WAVEFRONT_RAYS: r->wavefront_rays = std::max<uint64_t>(value, 64u); break;
     case LPT_OPT_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_REFILL: 0..63"); r->refill = (int)value; break;
@@ -1645,7 +1646,12 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         }
         stage_end(r, s);
 
-        const bool packet = r->packet_primary && r->merge_trace;
+        // Bounce 0 by packet traversal (one tree walk per 8x8-pixel patch) pays while the patch is narrow: at 1920x1080 a packet enters 17.9 nodes
+        // for rays that need 14.9 each, and the walk runs at 11.5 Grays/s against 6.2 per ray; at 240x135 the same patch spans eight times the
+        // angle, the walk visits several times the nodes, and the packet launch is a third of the frame (0.43 of 1.37 ms; 0.39 ms at 480x270,
+        // where the per-ray launch needs 0.13).  LPT_OPT_PACKET_PRIMARY 2 (default): packets up to 1.8 mrad per pixel; 1: always; 0: never.
+        const float pixel_rad = 2.0f * th / (float)std::max(r->h, 1u);
+        const bool packet = r->merge_trace && (r->packet_primary == 1u || (r->packet_primary == 2u && pixel_rad <= kPacketMaxPixelRad));
         tk.packet = packet;
         uint32_t seed = seed0;
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
@@ -1677,7 +1683,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         }
         // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
         // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
-        const bool path = packet && r->path_rays && n_rays <= r->path_rays;
+        const bool path = r->merge_trace && r->path_rays && n_rays <= r->path_rays;   // the primary hits are there, whichever kernel found them
         if (path) {
             stage_begin(r, ST_PATH, s);
             const uint32_t pblocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), std::max(8u, (cus * r->path_waves_per_cu) & ~7u));

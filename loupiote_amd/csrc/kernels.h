@@ -72,6 +72,7 @@ struct FrameCounters {
     // different heads do not serialise on one L2 line
     uint32_t ihead[kMaxBounces * 8 * 32];
     uint32_t shead[kMaxBounces * 8 * 32];
+    uint32_t phead[8 * 32];       // k_path's own chunk heads over the bounce-0 queue (ihead[0] may have been drained by a per-ray bounce-0 launch)
     uint32_t shaded[kMaxBounces];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
     unsigned long long wave_steps, live_lanes, node_lanes, tri_lanes;  // closest-hit kernel, stats only
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, D
     for (int k = 0; k < 3; ++k) s_cnt[lane + 64u * k] = 0u;   // kMaxBounces == 64
     __syncthreads();
     ChunkPuller pl;
-    puller_init(pl, &ctr->ihead[0], ctr->qcount[0]);
+    puller_init(pl, &ctr->phead[0], ctr->qcount[0]);
     const uint32_t nb = p.max_bounces;
     const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
     const int min_batch = 64 - refill;

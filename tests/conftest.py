@@ -47,5 +47,7 @@ def pipeline(request, monkeypatch):
     the wavefront's ray count (LPT_OPT_PATH_RAYS); both must give the oracle's frame at every size.  Modules opt in with
     `pytestmark = pytest.mark.usefixtures("pipeline")`."""
     from loupiote_amd import api
-    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF if request.param == "path" else 0})
+    # the "path" arm also forces bounce 0 through the packet kernel at every resolution (the default picks it by pixel footprint: not for the
+    # small frames most tests render), the "per_bounce" arm leaves that choice to the library
+    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF, "packet_primary": 1} if request.param == "path" else {"path_rays": 0})
     return request.param

@@ -257,23 +257,26 @@ def test_read_pixels_and_blit_of_a_recorded_frame_travel_piece_by_piece_too(devi
 
 
 def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_glb):
-    """The default: bounce 0 by packet traversal (k_trace_packet: one tree walk per 64 coherent rays), then — for a wavefront this small —
-    every later bounce in ONE launch (k_path); path_rays = 0 selects the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace, one
+    """The default for a frame this small: bounce 0 per ray (packet traversal, k_trace_packet: one tree walk per 8x8-pixel patch, is chosen by pixel
+    footprint — packet_primary = 1 forces it), then every later bounce in ONE launch (k_path); path_rays = 0 selects the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace, one
     memory round trip per traversal step: ray_step_pipe), pipe_rays = 0 their two-round-trip step, packet_primary = 0 per-ray traversal
     for bounce 0 too, merge_trace = 0 the split k_intersect / k_shadow launches.  The order of the tests differs, the frame and the ray
     counts do not (lpt_renderer_set_option: no environment variable selects a kernel)."""
     _, sg, pr = cornell
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
-    variants = ({}, {"path_rays": 0}, {"path_rays": 0, "pipe_rays": 0}, {"path_rays": 0, "pipe_rays": 30000}, {"merge_trace": 0}, {"packet_primary": 0},
-                {"packet_primary": 0, "pipe_rays": 0}, {"path_waves_per_cu": 3, "path_refill": 20}, {"path_refill": 63}, {"path_refill": 0})
+    variants = ({}, {"packet_primary": 1}, {"path_rays": 0}, {"path_rays": 0, "packet_primary": 1}, {"path_rays": 0, "pipe_rays": 0, "packet_primary": 1},
+                {"path_rays": 0, "pipe_rays": 30000}, {"merge_trace": 0}, {"packet_primary": 0}, {"packet_primary": 0, "pipe_rays": 0},
+                {"path_waves_per_cu": 3, "path_refill": 20, "packet_primary": 1}, {"path_refill": 63}, {"path_refill": 0})
     for opts in variants:
         r = _renderer(device, sg, pr, 0, options=opts)
         assert all(r.get_option(k) == v for k, v in opts.items())
+        packet = r.get_option("packet_primary")       # the suite's `pipeline` fixture forces 1 in its "path" arm
         for _ in range(4):
             r.raytrace(view)
         assert r.read_radiance().tobytes() == ref.tobytes(), opts
         c = r.ray_counts()
         assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded), opts
-        assert c.primary == (0 if ("packet_primary" in opts or "merge_trace" in opts) else 4 * W * H), opts   # which kernel traced bounce 0
+        # which kernel traced bounce 0: packets only where asked for — the default (2) picks by pixel footprint, and a frame this small is traced per ray
+        assert c.primary == (4 * W * H if packet == 1 and "merge_trace" not in opts else 0), opts
         r.close()
