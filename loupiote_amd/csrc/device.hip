@@ -1679,7 +1679,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
                 else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
                 stage_end(r, s);
-            } else trace(0, -1);
+            } else if (!(r->path_rays && n_rays <= r->path_rays)) trace(0, -1);   // a path-kernel wavefront traces its primary rays itself
         }
         // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
         // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
@@ -1689,10 +1689,10 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             const uint32_t pblocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), std::max(8u, (cus * r->path_waves_per_cu) & ~7u));
             const size_t plds = lds + kPathLdsExtra;   // stacks + sRGB table + per-bounce counters
             if (denoise) {
-                if (r->stats) hipLaunchKernelGGL((k_path<true, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
-                else hipLaunchKernelGGL((k_path<true, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
-            } else if (r->stats) hipLaunchKernelGGL((k_path<false, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
-            else hipLaunchKernelGGL((k_path<false, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], wf.hits, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+                if (r->stats) hipLaunchKernelGGL((k_path<true, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+                else hipLaunchKernelGGL((k_path<true, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+            } else if (r->stats) hipLaunchKernelGGL((k_path<false, true>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
+            else hipLaunchKernelGGL((k_path<false, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
             stage_end(r, s);
         }
         for (uint32_t b = 0; b < nb && !path; ++b) {

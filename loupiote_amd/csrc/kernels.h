@@ -1443,14 +1443,21 @@ __global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, D
                 if (!(pl.next < pl.end) || imask == 0ull) break;
                 const uint32_t idx = pl.next + (uint32_t)__popcll(imask & ((1ull << lane) - 1ull));
                 if (phase == 0u && idx < pl.end) {
-                    const float4 d4 = ld_nt(q0.d + idx), h4 = ld_nt(hits0 + idx);
+                    const float4 d4 = ld_nt(q0.d + idx);
                     pxy = __float_as_uint(q0.T[idx].w);
-                    rs.o = p.origin; rs.d = mk3(d4.x, d4.y, d4.z);
-                    rs.best.t = h4.x; rs.best.u = h4.y; rs.best.v = h4.z; rs.best.prim = __float_as_uint(h4.w);
                     vslot = __float_as_uint(d4.w);
                     T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
                     pdf = -1.0f; bounce = 0u;
-                    phase = 2u;
+                    if (hits0) {   // wave-uniform: the primary hits are there (k_trace_packet has run)
+                        const float4 h4 = ld_nt(hits0 + idx);
+                        rs.o = p.origin; rs.d = mk3(d4.x, d4.y, d4.z);
+                        rs.best.t = h4.x; rs.best.u = h4.y; rs.best.v = h4.z; rs.best.prim = __float_as_uint(h4.w);
+                        phase = 2u;
+                    } else {       // no packet launch for this frame (wide pixels): the lane traces its primary ray itself
+                        ray_begin(rs, p.origin, mk3(d4.x, d4.y, d4.z), LPT_T_INF);
+                        shadow = false;
+                        phase = 1u;
+                    }
                 }
                 pl.next = min(pl.end, pl.next + (uint32_t)__popcll(imask));
             }
