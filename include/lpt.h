@@ -526,11 +526,16 @@ typedef enum lpt_option {
     LPT_OPT_SHADE_BLOCKS_PER_CU = 7,/* shading pass: blocks per CU (default 4) */
     LPT_OPT_PATH_RAYS = 8,          /* wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (the
                                      * path kernel: no chip-wide barrier per bounce — small frames and the tile shards of a wide multi-GPU
-                                     * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 800 000, the
+                                     * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 450 000, the
                                      * measured cross-over; 0: never */
     LPT_OPT_PATH_WAVES_PER_CU = 9,  /* path kernel: persistent waves per CU (default 16) */
     LPT_OPT_PATH_REFILL = 10,       /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
-    LPT_OPT_OCC_CELL_MILLI = 11     /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
+    LPT_OPT_OCC_CELL_MILLI = 11,    /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
+    LPT_OPT_STEP_BUDGET = 12,       /* per-bounce traversal launches: a ray not finished after this many steps is dropped by the per-lane kernel and traced
+                                     * again by a whole wave (k_trace_coop: eight lanes per node), so that the one ray in 10^5 that needs hundreds of steps
+                                     * does not set the duration of the launch; default 48, 0 = off */
+    LPT_OPT_BUDGET_RAYS = 13        /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
+                                     * value applies the budget to every wavefront up to it) */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

@@ -157,6 +157,7 @@ struct Wavefront {
     Queue q[2]{};
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr;
+    uint32_t *strag = nullptr;      // the stragglers of a traversal launch (k_trace's step budget -> k_trace_coop): ray index | shadow << 31
     FrameCounters *ctr = nullptr;
     size_t ray_cap = 0;             // rays (pixel slots x samples) the per-ray buffers can hold; 0 = not allocated yet
     hipEvent_t done = nullptr;      // recorded on `stream` behind the lane's last traversal / shading launch
@@ -164,9 +165,10 @@ struct Wavefront {
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
+constexpr uint32_t kStepBudget = 48u, kBudgetRays = 3000000u;  // defaults of LPT_OPT_STEP_BUDGET / LPT_OPT_BUDGET_RAYS (measured: profiles/r04_experiments_ab.txt H)
 constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to this angle per pixel (measured: 1.53 mrad, 960x540: packets 4.46 against 4.51 ms; 2.05 mrad, 720x405: 3.32 against 3.20)
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
-constexpr uint32_t kPathRays = 800000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over
+constexpr uint32_t kPathRays = 450000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over against the per-bounce launches WITH their step budget
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
@@ -231,6 +233,9 @@ struct lpt_renderer {
     hipEvent_t xevent = nullptr;
     bool xevent_recorded = false;
     Totals *totals = nullptr;
+    // per-bounce traversal launches: a ray that is not finished after this many steps is handed to k_trace_coop (a whole wave per ray); 0 = off.
+    // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
+    uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
     uint32_t *occ_table = nullptr;   // occluder-cache probe (stats only): kOccEntries leaf slots + 1, zero = empty; allocated by enable_stats
     float occ_cell = 0.25f;          // its grid cell (scene units); LPT_OPT_OCC_CELL_MILLI
     void *default_probe = nullptr;
@@ -1016,10 +1021,11 @@ static int alloc_denoiser(lpt_renderer *r) {
 }
 
 static void free_ray_buffers(Wavefront &wf) {
-    void *ptrs[] = {wf.q[0].o, wf.q[0].d, wf.q[0].T, wf.q[1].o, wf.q[1].d, wf.q[1].T, wf.sq.o, wf.sq.d, wf.sq.c, wf.hits, wf.Lsum};
+    void *ptrs[] = {wf.q[0].o, wf.q[0].d, wf.q[0].T, wf.q[1].o, wf.q[1].d, wf.q[1].T, wf.sq.o, wf.sq.d, wf.sq.c, wf.hits, wf.Lsum, wf.strag};
     for (void *p : ptrs) if (p) hipFree(p);
     wf.q[0] = Queue{}; wf.q[1] = Queue{}; wf.sq = ShadowQueue{};
     wf.hits = wf.Lsum = nullptr;
+    wf.strag = nullptr;
     wf.ray_cap = 0;
 }
 
@@ -1123,6 +1129,7 @@ static int alloc_ray_buffers(Wavefront &wf, size_t rays) {
     HIP_TRY(hipMalloc(&wf.sq.c, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&wf.hits, sizeof(float4) * n));
     HIP_TRY(hipMalloc(&wf.Lsum, sizeof(float4) * n));
+    HIP_TRY(hipMalloc(&wf.strag, sizeof(uint32_t) * 2 * n));   // a launch carries at most n closest-hit + n shadow rays
     wf.ray_cap = n;
     return LPT_OK;
 }
@@ -1406,6 +1413,8 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_PATH_WAVES_PER_CU: if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
     case LPT_OPT_PATH_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
     case LPT_OPT_OCC_CELL_MILLI: r->occ_cell = (float)std::min<uint64_t>(value, 1000000u) * 1.0e-3f; break;
+    case LPT_OPT_STEP_BUDGET: r->step_budget = (uint32_t)std::min<uint64_t>(value, 1u << 20); break;
+    case LPT_OPT_BUDGET_RAYS: r->budget_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1424,6 +1433,8 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_PATH_WAVES_PER_CU: *value = r->path_waves_per_cu; break;
     case LPT_OPT_PATH_REFILL: *value = (uint64_t)r->path_refill; break;
     case LPT_OPT_OCC_CELL_MILLI: *value = (uint64_t)(r->occ_cell * 1000.0f + 0.5f); break;
+    case LPT_OPT_STEP_BUDGET: *value = r->step_budget; break;
+    case LPT_OPT_BUDGET_RAYS: *value = r->budget_rays; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1534,7 +1545,7 @@ struct Ticket {
 // [slot0, slot0 + piece_slots) — ray generation, traversal, shading — on the wavefront's lane, from the protocol state the first
 // of the calls saw (frame_count0, seed0, acc0 = its accumulate flag; the later ones ran with accumulate == true by construction).
 static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_samples, uint32_t frame_count0, uint32_t seed0, bool acc0,
-                           uint32_t slot0, uint32_t piece_slots, Ticket &tk) {
+                           uint32_t slot0, uint32_t piece_slots, Ticket &tk, bool solo) {
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     hipStream_t sm = r->stream;                  // accumulation, filter passes, bookkeeping, reads, the exchange: in call order
     const uint32_t nb = r->max_bounces;          // reference constant 3 (:398-399)
@@ -1660,14 +1671,22 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // the occluder-cache probe rides with the stats kernels only (kernels.h OccProbe); its table belongs to the renderer
         OccProbe occ{nullptr, 0u, 0.0f};
         if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
+        // the step budget pays where nothing else fills the tail of a launch: a submission that is ONE wavefront (a tile shard, a small frame).  The
+        // pieces of a cut batch overlap on the renderer's lanes and hide each other's tails: 1/2 shard as two wavefronts 6.84 ms without, 6.93 with it
+        const uint32_t budget = (r->step_budget && (solo || r->budget_rays > kBudgetRays) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
+            const int launch_no = cb >= 0 ? cb : (int)nb;   // which strag_count[] this launch fills
             if (pipe) {
-                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
-                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
-            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ);
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+            if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
+                if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * 32u), dim3(kTraceBlock), 0, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+                else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * 32u), dim3(kTraceBlock), 0, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+            }
             stage_end(r, s);
         };
         if (r->merge_trace) {
@@ -1809,7 +1828,7 @@ static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
     Ticket tk[kMaxLanes];
     if (!granules) {   // nothing owned (a compositor rank): one empty wavefront keeps the bookkeeping of the call
         r->n_wavefronts++;
-        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, 0u, 0u, tk[0]);
+        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, 0u, 0u, tk[0], true);
         return st != LPT_OK ? st : wavefront_finish(r, tk[0], nullptr, 0u, 0u);
     }
     // The first halves run ahead of the second halves by the number of lanes: wavefront k's launches are enqueued before the
@@ -1836,7 +1855,7 @@ static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
         if (k >= ahead) { const int st = finish(k - ahead); if (st != LPT_OK) return bail(st); }
         const uint32_t g0 = k * per_piece, g1 = std::min(granules, g0 + per_piece);
         r->n_wavefronts++;
-        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule, tk[k % ahead]);
+        const int st = wavefront_trace(r, b.view, b.n, b.frame_count0, b.seed0, b.acc0, g0 * granule, (g1 - g0) * granule, tk[k % ahead], pieces == 1u);
         if (st != LPT_OK) return bail(st);
     }
     for (uint32_t k = pieces > ahead ? pieces - ahead : 0u; k < pieces; ++k) { const int st = finish(k); if (st != LPT_OK) return bail(st); }

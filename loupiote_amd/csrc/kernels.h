@@ -72,6 +72,9 @@ struct FrameCounters {
     // different heads do not serialise on one L2 line
     uint32_t ihead[kMaxBounces * 8 * 32];
     uint32_t shead[kMaxBounces * 8 * 32];
+    // the stragglers of a traversal launch (k_trace with a step budget): rays that were not finished within the budget, re-traced by k_trace_coop;
+    // one count per launch of a wavefront (index: the bounce of its closest-hit rays, max_bounces for the last, shadow-only launch)
+    uint32_t strag_count[kMaxBounces + 1];
     uint32_t phead[8 * 32];       // k_path's own chunk heads over the bounce-0 queue (ihead[0] may have been drained by a per-ray bounce-0 launch)
     uint32_t shaded[kMaxBounces];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
@@ -691,7 +694,7 @@ __device__ __forceinline__ uint32_t occ_key(const OccProbe &oc, f3 o) {
 // PIPE: ray_step_pipe (one memory round trip per step) instead of ray_step_any — same results, for launches of few rays.
 template <bool STATS, bool PIPE = false>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
-                                                       int cb, int sb, int refill, OccProbe occ) {
+                                                       int cb, int sb, int refill, OccProbe occ, uint32_t budget, uint32_t *strag, int launch) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pc, ps;
     puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : ctr->qcount[cb]);
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
     uint32_t n_occluded = 0, n_found = 0, n_would = 0;        // occluder-cache probe (STATS)
-    uint32_t my_steps = 0;                                    // traversal steps of the ray in hand (STATS)
+    uint32_t my_steps = 0;                                    // traversal steps of the ray in hand (STATS; the step budget)
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
@@ -755,6 +758,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
                     float4 o4, d4;
                     if (use_s) { o4 = sq.o[idx]; d4 = sq.d[idx]; } else { o4 = q.o[idx]; d4 = q.d[idx]; }
                     ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), use_s ? o4.w : LPT_T_INF);
+                    my_steps = 0;
                     if (use_s) rs.best.u = d4.w;   // kept for the deposit; a hit overwrites it, and then nothing is deposited
                     ray = idx;
                     shadow = use_s;
@@ -770,10 +774,18 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             w_live += (uint32_t)__popcll(__ballot(active));
             w_node += (uint32_t)__popcll(__ballot(PIPE ? active && rs.tg2.y == 0u && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0) : active && rs.tg.y == 0u));
         }
-        if (STATS && active) my_steps++;
+        if ((STATS || budget) && active) my_steps++;
         if (active && (PIPE ? ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt) : ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt))) {
             active = false;
             finished = true;
+        }
+        // STEP BUDGET: one ray in 10^4..10^5 needs 64..360 steps, and a launch lasts as long as its longest ray.  A ray that has used
+        // its budget is dropped here — unfinished, its lane free for the next ray — and listed for k_trace_coop, which traces it again with a whole
+        // wave (eight lanes per node, every pending node of the ray in one round).  Hits are decided by the Woop test alone, so the result is the same.
+        if (budget && active && my_steps >= budget) {
+            strag[atomicAdd(&ctr->strag_count[launch], 1u)] = ray | (shadow ? 0x80000000u : 0u);
+            active = false;
+            if (!STATS) my_steps = 0;
         }
         if (STATS) {
             w_tri += (uint32_t)__popcll(__ballot(dt != 0u));
@@ -796,6 +808,140 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             atomicAdd(&ctr->node_lanes, (unsigned long long)w_node);
             atomicAdd(&ctr->tri_lanes, (unsigned long long)w_tri);
         }
+    }
+}
+
+// The stragglers of a traversal launch, each traced by a WHOLE WAVE: eight lanes per node (lane j of a group tests child j), up to eight pending
+// nodes of the ray per round, so a ray that would take a lane 100-360 dependent steps takes the wave 15-40 rounds.  The node stack (node indices)
+// is one LDS column per wave.  A lane tests the triangles of the leaf child it found; a round's candidates are merged by the rule of the per-lane
+// traversal — the smallest t, ties to the lower primitive id — through a 64-bit key, so the hit (t, u, v, prim) is the one k_trace finds: the slab
+// tests are conservative on both sides and only the Woop test decides (SPEC §7).  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
+constexpr uint32_t kCoopStack = 384u;   // node indices; a round pops m nodes and pushes at most 8 m: m is limited to what fits
+template <bool STATS>
+__global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
+                                                            int cb, int sb, const uint32_t *strag, int launch) {
+    static_assert(kTraceBlock == 64, "one wave per block: the LDS stack is the wave's");
+    __shared__ uint32_t stk[kCoopStack + 8u];   // + 8: the last round before the limit may push one node's eight children
+    const uint32_t lane = threadIdx.x, grp = lane >> 3, c = lane & 7u;
+    const uint32_t n_strag = ctr->strag_count[launch];
+    uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
+    for (uint32_t si = blockIdx.x; si < n_strag; si += gridDim.x) {
+        const uint32_t e = strag[si];
+        const bool shadow = (e >> 31) != 0u;
+        const uint32_t ray = e & 0x7FFFFFFFu;
+        const float4 o4 = shadow ? sq.o[ray] : q.o[ray], d4 = shadow ? sq.d[ray] : q.d[ray];
+        const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+        const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+        Hit best;
+        best.t = shadow ? o4.w : LPT_T_INF; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;
+        uint32_t count = 1u;            // wave-uniform
+        if (lane == 0) stk[0] = 0u;     // the root
+        __syncthreads();
+        bool done = false;
+        while (count && !done) {
+            const uint32_t m = min(min(count, 8u), max((kCoopStack - count) / 7u, 1u));
+            const bool work = grp < m;
+            uint32_t node = 0u;
+            if (work) node = stk[count - 1u - grp];
+            __syncthreads();            // every pop is read before the pushes below overwrite the slots
+            count -= m;
+            bool hit_inner = false, hit_leaf = false;
+            uint32_t child = 0u, first = 0u, bits = 0u;
+            if (work) {
+                const DNode8 *n = sc.nodes + node;
+                const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
+                const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
+                const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
+                const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
+                const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
+                const float bx = (__uint_as_float(n0.x) - o.x) * ix;
+                const float by = (__uint_as_float(n0.y) - o.y) * iy;
+                const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+                const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
+                const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
+                const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
+                const uint32_t sh = 8u * (c & 3u);
+                const bool hi4 = c >= 4u;
+                const uint32_t lox = ((hi4 ? n2.y : n2.x) >> sh) & 0xFFu, loy = ((hi4 ? n2.w : n2.z) >> sh) & 0xFFu, loz = ((hi4 ? n3.y : n3.x) >> sh) & 0xFFu;
+                const uint32_t hix = ((hi4 ? n3.w : n3.z) >> sh) & 0xFFu, hiy = ((hi4 ? n4.y : n4.x) >> sh) & 0xFFu, hiz = ((hi4 ? n4.w : n4.z) >> sh) & 0xFFu;
+                const float tnx = fmaf((float)(negx ? hix : lox), ax, bx - ex), tfx = fmaf((float)(negx ? lox : hix), ax, bx + ex);
+                const float tny = fmaf((float)(negy ? hiy : loy), ay, by - ey), tfy = fmaf((float)(negy ? loy : hiy), ay, by + ey);
+                const float tnz = fmaf((float)(negz ? hiz : loz), az, bz - ez), tfz = fmaf((float)(negz ? loz : hiz), az, bz + ez);
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+                const uint32_t imask = n0.w >> 24;
+                const uint32_t meta = ((hi4 ? n1.w : n1.z) >> sh) & 0xFFu;
+                const bool inner = ((imask >> c) & 1u) != 0u;
+                const bool hit = tn <= tf && meta != 0u;     // empty slots: meta 0 (their boxes are inverted as well)
+                hit_inner = hit && inner;
+                hit_leaf = hit && !inner;
+                child = n1.x + (uint32_t)__popc(imask & ~(0xFFFFFFFFu << c));
+                first = n1.y + (meta & 31u);
+                bits = meta >> 5;
+            }
+            if (STATS) { if (shadow) s_nodes += m; else n_nodes += m; }
+            // inner children: appended to the stack (ballot + prefix count)
+            const unsigned long long im = __ballot(hit_inner);
+            if (hit_inner) stk[count + (uint32_t)__popcll(im & ((1ull << lane) - 1ull))] = child;
+            count += (uint32_t)__popcll(im);
+            // leaf children: the lane tests its (up to three) triangles against the round's best
+            float ct = 0.f, cu = 0.f, cv = 0.f;
+            uint32_t cprim = 0xFFFFFFFFu;
+            bool cand = false;
+            if (hit_leaf) {
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    if (!((bits >> k) & 1u)) continue;
+                    const uint32_t ti = first + k;
+                    const float4 *w = sc.woop + 3u * (size_t)ti;
+                    const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+                    float t, u, v;
+                    if (ray_triangle(r0, r1, r2, o, d, cand ? ct : best.t, t, u, v)) {
+                        const uint32_t prim = sc.leaf_prim[ti];
+                        if (!cand || t < ct || prim < cprim) { ct = t; cu = u; cv = v; cprim = prim; cand = true; }
+                    }
+                }
+            }
+            if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(hit_leaf)); if (shadow) s_tris += nt; else n_tris += nt; }
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                if (shadow) { best.prim = 0u; done = true; }   // any hit in (0, tmax] occludes
+                else {
+                    // the wave's smallest (t, prim): t > 0, so its bit pattern orders like its value
+                    unsigned long long key = cand ? (((unsigned long long)__float_as_uint(ct) << 32) | cprim) : ~0ull;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const unsigned long long other = __shfl_xor(key, off);
+                        key = other < key ? other : key;
+                    }
+                    const unsigned long long old = ((unsigned long long)__float_as_uint(best.t) << 32) | best.prim;
+                    if (key < old) {
+                        const int src = __ffsll((long long)__ballot(cand && ((((unsigned long long)__float_as_uint(ct) << 32) | cprim) == key))) - 1;
+                        best.t = __shfl(ct, src); best.u = __shfl(cu, src); best.v = __shfl(cv, src); best.prim = __shfl(cprim, src);
+                    }
+                }
+            }
+            __syncthreads();            // the pushes are visible to the next round's pops
+        }
+        if (shadow) {
+            if (lane == 0 && best.prim == 0xFFFFFFFFu) {   // unoccluded: deposit the light sample
+                const uint32_t slot = __float_as_uint(d4.w);
+                const float4 cc = sq.c[ray];
+                float4 L = Lsum[slot];
+                L.x = L.x + cc.x; L.y = L.y + cc.y; L.z = L.z + cc.z;
+                Lsum[slot] = L;
+            }
+        } else {
+            intersect_lights(sc, o, d, best);
+            if (lane == 0) st_nt(hits + ray, make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)));
+        }
+        __syncthreads();                // the stack is reused by the wave's next ray
+    }
+    if (STATS && lane == 0) {
+        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
+        atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
     }
 }
 

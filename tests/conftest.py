@@ -49,5 +49,7 @@ def pipeline(request, monkeypatch):
     from loupiote_amd import api
     # the "path" arm also forces bounce 0 through the packet kernel at every resolution (the default picks it by pixel footprint: not for the
     # small frames most tests render), the "per_bounce" arm leaves that choice to the library
-    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF, "packet_primary": 1} if request.param == "path" else {"path_rays": 0})
+    # ... and runs its traversal launches with a step budget of 16 (default 48), so that in every parity test a good part of the rays is finished by the
+    # wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; wavefronts too large for the budget (the full-size vectors) run without
+    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF, "packet_primary": 1} if request.param == "path" else {"path_rays": 0, "step_budget": 16})
     return request.param

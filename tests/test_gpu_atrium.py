@@ -19,7 +19,7 @@ def atrium():
     return desc, osc
 
 
-def render_desc(device, desc, w, h, bounces, frames, rank=0, world=1, noise=None):
+def render_desc(device, desc, w, h, bounces, frames, rank=0, world=1, noise=None, options=None):
     scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, device)
     pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
@@ -31,6 +31,8 @@ def render_desc(device, desc, w, h, bounces, frames, rank=0, world=1, noise=None
     r.resize(device, sg, pr, (w, h))
     r.set_max_bounces(bounces)
     r.set_vfov(T.VFOV)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
     if world > 1:
         r.set_shard(rank, world)
         r.set_resources(device, sg, pr)
@@ -154,3 +156,17 @@ def test_raytrace_n_equals_n_sequential_calls(device, atrium):
     assert out[0][0].tobytes() == out[1][0].tobytes()
     assert out[0][1:] == out[1][1:]
     assert np.all(out[0][0][..., 3] == 1.0)
+
+
+@pytest.mark.parametrize("budget", [1, 9, 24])
+def test_step_budget_and_the_cooperative_kernel_give_the_same_frame(device, atrium, budget):
+    """per-bounce launches with a step budget (LPT_OPT_STEP_BUDGET): a ray that is not finished after `budget` traversal steps is dropped by the per-lane kernel
+    and traced again by a whole wave (k_trace_coop: eight lanes per node, up to eight pending nodes per round).  budget 1 sends every ray of bounces 1.. that way,
+    9 about half of them, 24 the long ones — the frame and the ray counts are the oracle's on the 262 144-triangle scene"""
+    desc, osc = atrium
+    from oracle import orc
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    acc, oc = osc.render(160, 90, view, T.VFOV, 6, frames=2, want_counters=True)
+    img, c, _ = render_desc(device, desc, 160, 90, 6, 2, options={"path_rays": 0, "step_budget": budget})
+    assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
+    assert img.tobytes() == orc.resolve(acc).tobytes()
