@@ -2124,8 +2124,13 @@ int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *
     HIP_TRY(hipStreamSynchronize(r->stream));
     const FrameCounters *ctr = r->wf[r->last_lane].ctr;
     if (!ctr) { if (closest) memset(closest, 0, sizeof(uint32_t) * n); if (shadow) memset(shadow, 0, sizeof(uint32_t) * n); return LPT_OK; }
-    if (closest && n) HIP_TRY(hipMemcpy(closest, ctr->qcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
-    if (shadow && n) HIP_TRY(hipMemcpy(shadow, ctr->shcount, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    // FrameCounters keeps (shadow count of bounce b, closest-hit count of bounce b + 1) side by side: unpack
+    uint32_t host[2 + 2 * kMaxBounces];
+    HIP_TRY(hipMemcpy(host, &ctr->q0, sizeof host, hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; b < n; ++b) {
+        if (closest) closest[b] = b == 0u ? host[0] : host[2u + 2u * (b - 1u) + 1u];
+        if (shadow) shadow[b] = host[2u + 2u * b];
+    }
     return LPT_OK;
 }
 

@@ -66,8 +66,11 @@ struct Queue { float4 *o; float4 *d; float4 *T; };
 struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w = pixel slot bits, c = contribution
 
 struct FrameCounters {
-    uint32_t qcount[kMaxBounces + 1];
-    uint32_t shcount[kMaxBounces];
+    // Queue sizes.  The shadow-ray count of bounce b and the closest-hit count of bounce b + 1 — the two queues ONE shading pass fills — sit side by
+    // side (qs[2b], qs[2b + 1]), so that a block reserves its slots in both with ONE 64-bit atomic (block_compact2) instead of two round trips;
+    // the primary rays' count has a word of its own.  Accessors: QC (closest-hit rays of bounce b), SC (shadow rays emitted by bounce b).
+    uint32_t q0, q0_pad;
+    uint32_t qs[2 * kMaxBounces];
     // chunk heads: 8 per bounce (one per XCD), each on its own 128-byte line so that the atomics of
     // different heads do not serialise on one L2 line
     uint32_t ihead[kMaxBounces * 8 * 32];
@@ -88,6 +91,8 @@ struct FrameCounters {
     uint32_t max_steps;
     uint32_t step_hist[12];
 };
+__device__ __host__ __forceinline__ uint32_t &QC(FrameCounters *c, int b) { return b == 0 ? c->q0 : c->qs[2 * (b - 1) + 1]; }
+__device__ __host__ __forceinline__ uint32_t &SC(FrameCounters *c, int b) { return c->qs[2 * b]; }
 struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes,
                                    primary, packet_nodes, packet_tris, shadow_occluded, occ_found, occ_hits; };   // mirrors lpt_ray_counts
 
@@ -210,6 +215,32 @@ __device__ __forceinline__ uint32_t block_compact(bool valid, uint32_t *counter,
     return idx;
 }
 
+// Two compactions with ONE global atomic: a block's slots in the shadow queue (valid_a, the low word of *pair) and in the next-bounce queue
+// (valid_b, the high word) are reserved together — one round trip to the L2 atomic unit and three barriers per block and iteration instead of
+// two and six (k_shade spends its time waiting: round 4).  Must be called by every thread of the block.  `lds` needs 12 uint32.
+__device__ __forceinline__ void block_compact2(bool valid_a, bool valid_b, unsigned long long *pair, uint32_t *lds, uint32_t &idx_a, uint32_t &idx_b) {
+    const unsigned long long ma = __ballot(valid_a), mb = __ballot(valid_b);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c0 = lds[0], c1 = lds[1], c2 = lds[2], c3 = lds[3];
+        const uint32_t a0 = c0 & 0xFFFFu, a1 = c1 & 0xFFFFu, a2 = c2 & 0xFFFFu, a3 = c3 & 0xFFFFu;
+        const uint32_t b0 = c0 >> 16, b1 = c1 >> 16, b2 = c2 >> 16, b3 = c3 >> 16;
+        const uint32_t ta = a0 + a1 + a2 + a3, tb = b0 + b1 + b2 + b3;
+        unsigned long long base = 0ull;
+        if (ta | tb) base = atomicAdd(pair, (unsigned long long)ta | ((unsigned long long)tb << 32));
+        const uint32_t ba = (uint32_t)base, bb = (uint32_t)(base >> 32);
+        lds[4] = ba; lds[5] = ba + a0; lds[6] = ba + a0 + a1; lds[7] = ba + a0 + a1 + a2;
+        lds[8] = bb; lds[9] = bb + b0; lds[10] = bb + b0 + b1; lds[11] = bb + b0 + b1 + b2;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    idx_a = lds[4 + wave] + (uint32_t)__popcll(ma & lt);
+    idx_b = lds[8 + wave] + (uint32_t)__popcll(mb & lt);
+    __syncthreads();  // lds is reused by the next call
+}
+
 // Sorted variant of block_compact (the "sorted shade / next-event stage" of the north star): the block's valid
 // elements are written in KEY order (8 keys: the direction octant of the ray), so that the 64 consecutive rays a
 // traversal wave pulls share one or two octants instead of eight.  Per wave and key one ballot + popcount, the
@@ -270,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
     // the tile area is only a multiple of 64: whole blocks stay in the loop for the barriers of block_compact
     const uint32_t total = p.n_slots * p.n_samples;
     const uint32_t rounded = (total + (kBlock - 1u)) & ~(uint32_t)(kBlock - 1u);
-    if (DENSE && blockIdx.x == 0 && threadIdx.x == 0) ctr->qcount[0] = total;   // the traversal launch behind this one reads it
+    if (DENSE && blockIdx.x == 0 && threadIdx.x == 0) QC(ctr, 0) = total;   // the traversal launch behind this one reads it
     for (uint32_t vslot = blockIdx.x * blockDim.x + threadIdx.x; vslot < rounded; vslot += stride) {
         const uint32_t sample = vslot / p.n_slots, slot = vslot - sample * p.n_slots;
         const uint32_t seed_counter = p.seed_counter + sample * p.max_bounces;
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(FrameParams p, DNoise nz, Que
                          (p.right.z * cx + p.up.z * cy) + p.fwd.z);
             d = normalize(dir);
         }
-        const uint32_t idx = DENSE ? vslot : block_compact(valid, &ctr->qcount[0], lds);
+        const uint32_t idx = DENSE ? vslot : block_compact(valid, &QC(ctr, 0), lds);
         if (valid) {
             st_nt(q.o + idx, make_float4(p.origin.x, p.origin.y, p.origin.z, -1.0f));
             st_nt(q.d + idx, make_float4(d.x, d.y, d.z, __uint_as_float(vslot)));
@@ -575,7 +606,7 @@ template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, int refill) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pl;
-    puller_init(pl, &ctr->ihead[bounce * 8 * 32], ctr->qcount[bounce]);
+    puller_init(pl, &ctr->ihead[bounce * 8 * 32], QC(ctr, bounce));
     const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
@@ -633,7 +664,7 @@ template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce, int refill) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pl;
-    puller_init(pl, &ctr->shead[bounce * 8 * 32], ctr->shcount[bounce]);
+    puller_init(pl, &ctr->shead[bounce * 8 * 32], SC(ctr, bounce));
     const uint32_t lane = threadIdx.x;
     uint32_t n_nodes = 0, n_tris = 0;
     RayState rs;
@@ -697,8 +728,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
                                                        int cb, int sb, int refill, OccProbe occ, uint32_t budget, uint32_t *strag, int launch) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pc, ps;
-    puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : ctr->qcount[cb]);
-    puller_init(ps, &ctr->shead[(sb < 0 ? 0 : sb) * 8 * 32], sb < 0 ? 0u : ctr->shcount[sb]);
+    puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : QC(ctr, cb));
+    puller_init(ps, &ctr->shead[(sb < 0 ? 0 : sb) * 8 * 32], sb < 0 ? 0u : SC(ctr, sb));
     if (cb < 0) pc.dry = true;
     if (sb < 0) ps.dry = true;
     const uint32_t lane = threadIdx.x;
@@ -985,7 +1016,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
     const DNode8 *__restrict__ nodes = sc.nodes;
     const float4 *__restrict__ woop = sc.woop;
     const uint32_t *__restrict__ leaf_prim = sc.leaf_prim;
-    const uint32_t count = ctr->qcount[bounce];
+    const uint32_t count = QC(ctr, bounce);
     const uint32_t lane = threadIdx.x;
     uint32_t visits = 0, tests = 0;
     for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
@@ -1446,7 +1477,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
     __shared__ uint8_t s_perm[REGROUP ? 256 : 4];
     s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];  // kBlock == 256
     __syncthreads();
-    const uint32_t count = ctr->qcount[bounce];
+    const uint32_t count = QC(ctr, bounce);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounded = (count + 255u) & ~255u;  // keep whole blocks in the loop for the barriers
     uint32_t n_surface = 0;
@@ -1507,13 +1538,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                             }, so);
         }
         // `sorted` (wave-uniform; bit 0: next-bounce queue, bit 1: shadow queue): the queue leaves the block ordered by direction octant
-        const uint32_t si = (sorted & 2) ? block_compact_binned(so.want_shadow, so.want_shadow ? dir_octant(so.sd4.x, so.sd4.y, so.sd4.z) : 0u, &ctr->shcount[bounce], lds)
-                                   : block_compact(so.want_shadow, &ctr->shcount[bounce], lds);
-        if (so.want_shadow) { st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
-        if (!last_bounce) {
-            const uint32_t ni = (sorted & 1) ? block_compact_binned(so.want_next, so.want_next ? dir_octant(so.nd4.x, so.nd4.y, so.nd4.z) : 0u, &ctr->qcount[bounce + 1], lds)
-                                       : block_compact(so.want_next, &ctr->qcount[bounce + 1], lds);
-            if (so.want_next) { st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
+        if (!(sorted & 3)) {   // the default: both queues' slots with one atomic (the last bounce emits no next ray: its word gets + 0)
+            uint32_t si, ni;
+            block_compact2(so.want_shadow, so.want_next && !last_bounce, reinterpret_cast<unsigned long long *>(&SC(ctr, bounce)), lds, si, ni);
+            if (so.want_shadow) { st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
+            if (!last_bounce && so.want_next) { st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
+        } else {
+            const uint32_t si = (sorted & 2) ? block_compact_binned(so.want_shadow, so.want_shadow ? dir_octant(so.sd4.x, so.sd4.y, so.sd4.z) : 0u, &SC(ctr, bounce), lds)
+                                       : block_compact(so.want_shadow, &SC(ctr, bounce), lds);
+            if (so.want_shadow) { st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
+            if (!last_bounce) {
+                const uint32_t ni = (sorted & 1) ? block_compact_binned(so.want_next, so.want_next ? dir_octant(so.nd4.x, so.nd4.y, so.nd4.z) : 0u, &QC(ctr, bounce + 1), lds)
+                                           : block_compact(so.want_next, &QC(ctr, bounce + 1), lds);
+                if (so.want_next) { st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
+            }
         }
         n_surface += so.is_surface ? 1u : 0u;
     }
@@ -1560,7 +1598,7 @@ __global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, D
     for (int k = 0; k < 3; ++k) s_cnt[lane + 64u * k] = 0u;   // kMaxBounces == 64
     __syncthreads();
     ChunkPuller pl;
-    puller_init(pl, &ctr->phead[0], ctr->qcount[0]);
+    puller_init(pl, &ctr->phead[0], QC(ctr, 0));
     const uint32_t nb = p.max_bounces;
     const float inv_nl = sc.n_lights ? 1.0f / (float)sc.n_lights : 0.0f;
     const int min_batch = 64 - refill;
@@ -1672,9 +1710,9 @@ __global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, D
         }
     }
     __syncthreads();
-    if (lane >= 1u && lane <= nb && s_cnt[lane]) atomicAdd(&ctr->qcount[lane], s_cnt[lane]);
+    if (lane >= 1u && lane <= nb && s_cnt[lane]) atomicAdd(&QC(ctr, lane), s_cnt[lane]);
     if (lane < nb) {
-        if (s_cnt[64u + lane]) atomicAdd(&ctr->shcount[lane], s_cnt[64u + lane]);
+        if (s_cnt[64u + lane]) atomicAdd(&SC(ctr, lane), s_cnt[64u + lane]);
         if (s_cnt[128u + lane]) atomicAdd(&ctr->shaded[lane], s_cnt[128u + lane]);
     }
     if (STATS) {
@@ -1918,9 +1956,9 @@ __global__ __launch_bounds__(kBlock) void k_debug_view(const uint4 *gb, const fl
 
 __global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces, uint32_t packet_primary) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (packet_primary) { tot->primary += ctr->qcount[0]; tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
+    if (packet_primary) { tot->primary += QC(ctr, 0); tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
     unsigned long long c = 0, s = 0, sh = 0;
-    for (uint32_t b = 0; b < bounces; ++b) { c += ctr->qcount[b]; s += ctr->shcount[b]; sh += ctr->shaded[b]; }
+    for (uint32_t b = 0; b < bounces; ++b) { c += QC(ctr, b); s += SC(ctr, b); sh += ctr->shaded[b]; }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
