@@ -1684,8 +1684,9 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
             else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
             if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
-                if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * 32u), dim3(kTraceBlock), 0, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
-                else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * 32u), dim3(kTraceBlock), 0, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+                const size_t clds = sizeof(uint32_t) * coop_stack_entries(r->sg->stats.max_depth);
+                if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * 32u), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+                else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * 32u), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
             }
             stage_end(r, s);
         };

@@ -847,12 +847,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
 // is one LDS column per wave.  A lane tests the triangles of the leaf child it found; a round's candidates are merged by the rule of the per-lane
 // traversal — the smallest t, ties to the lower primitive id — through a 64-bit key, so the hit (t, u, v, prim) is the one k_trace finds: the slab
 // tests are conservative on both sides and only the Woop test decides (SPEC §7).  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
-constexpr uint32_t kCoopStack = 384u;   // node indices; a round pops m nodes and pushes at most 8 m: m is limited to what fits
+// Node indices.  A round pops m <= 8 nodes and pushes at most 8 m.  Up to kCoopStack entries the walk is as broad as it can be; beyond, m = 1: depth first,
+// which adds at most 7 entries per level below the node it pops — the host sizes the LDS column for kCoopStack + 8 + 7 * (tree depth + 1) entries
+// (coop_stack_bytes), so the column cannot overflow whatever the ray's frontier looks like.
+constexpr uint32_t kCoopStack = 384u;
+__host__ __device__ __forceinline__ uint32_t coop_stack_entries(uint32_t tree_depth) { return kCoopStack + 8u + 7u * (tree_depth + 1u); }
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
                                                             int cb, int sb, const uint32_t *strag, int launch) {
     static_assert(kTraceBlock == 64, "one wave per block: the LDS stack is the wave's");
-    __shared__ uint32_t stk[kCoopStack + 8u];   // + 8: the last round before the limit may push one node's eight children
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // coop_stack_entries(depth) node indices (host)
     const uint32_t lane = threadIdx.x, grp = lane >> 3, c = lane & 7u;
     const uint32_t n_strag = ctr->strag_count[launch];
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
@@ -871,7 +875,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, 
         __syncthreads();
         bool done = false;
         while (count && !done) {
-            const uint32_t m = min(min(count, 8u), max((kCoopStack - count) / 7u, 1u));
+            const uint32_t room = count < kCoopStack ? kCoopStack - count : 0u;
+            const uint32_t m = min(min(count, 8u), max(room / 7u, 1u));
             const bool work = grp < m;
             uint32_t node = 0u;
             if (work) node = stk[count - 1u - grp];
