@@ -71,8 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--texture-size", type=int, default=1024, help="experiments only (SURVEY §8d: 1024)")
     ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, communicator, exchange) even with one rank")
-    ap.add_argument("--exchange", choices=["gather", "reduce"], default="gather",
-                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv) or the dense ncclReduce of the accumulation buffer")
+    ap.add_argument("--exchange", choices=["gather", "reduce", "host"], default="gather",
+                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv), the dense ncclReduce of the accumulation buffer, or "
+                         "`host`: no exchange on the GPUs — every rank writes its owned pixels straight into ONE shared-memory frame (lpt_renderer_read_radiance_owned; "
+                         "each GPU's 1/N over its own PCIe link), completed by a host-side barrier")
     ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
     ap.add_argument("--root-weight", type=int, default=0, help="N>1: tile-ownership weight of rank 0 against 8 for every other rank (lpt_renderer_set_shard_weighted): "
@@ -343,9 +345,10 @@ def run(args):
     extras = not args.no_extras
     # frames in flight over several communicators has never run on more than one GPU: on N>1 it is opt-in, so that an
     # untested leg cannot take the headline measurement down with it
-    tp_leg = extras and (world == 1 or args.throughput)
+    tp_leg = extras and (world == 1 or (args.throughput and args.exchange != "host"))
+    host_gather = args.exchange == "host" and world > 1
     comms = []
-    if use_dist:
+    if use_dist and not host_gather:
         # one communicator for the timed renderer + one per pipelined renderer of the throughput measurement: RCCL serialises
         # the operations of ONE communicator, so frames in flight must not share one
         n_comms = 1 + (P if tp_leg else 0)
@@ -354,6 +357,32 @@ def run(args):
         for uid in box[0]:
             comms.append(lp.Comm(dev, uid, rank, world))   # ncclCommInitRank inside the library (RCCL over xGMI)
     xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
+    # host-side gather: ONE frame in POSIX shared memory that every rank maps and page-locks, + a line of per-rank progress words for the frame barrier
+    shared = None
+    if host_gather:
+        box = [("/dev/shm/lpt_frame_%d_%d" % (os.getpid(), int(time.time() * 1e6))) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        shm_path = box[0]
+        n_f32 = HEIGHT * WIDTH * 4
+        if rank == 0:
+            np.memmap(shm_path, dtype=np.float32, mode="w+", shape=(n_f32 + 64 * 16,)).flush()
+        dist.barrier()
+        whole = np.memmap(shm_path, dtype=np.float32, mode="r+", shape=(n_f32 + 64 * 16,))
+        lp.host_register(whole)
+        shared = {"frame": whole[:n_f32].reshape(HEIGHT, WIDTH, 4), "words": whole[n_f32:].view(np.int32), "path": shm_path, "whole": whole, "no": 0}
+
+    def host_frame_barrier():
+        """every rank has written frame `no` (its word = no), rank 0 has seen all of them (word 16 * world = no): polling on shared memory, microseconds"""
+        shared["no"] += 1
+        no, wds = shared["no"], shared["words"]
+        wds[16 * rank] = no
+        if rank == 0:
+            while any(int(wds[16 * q]) < no for q in range(world)):
+                pass
+            wds[16 * world] = no
+        else:
+            while int(wds[16 * world]) < no:
+                pass
     desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"), texture_size=args.texture_size)
     tex_bytes = int(sum(im.size for im in desc["images"]))
     scene = scenes.to_product(desc)
@@ -390,6 +419,9 @@ def run(args):
         if comm is not None:
             rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)
+        elif host_gather:
+            rr.set_shard(rank, world, 32, 8, weights=weights[0])
+            rr.set_resources(dev, sg, probe)
         elif shard > 1:
             rr.set_shard(0, shard, 32, 8)
             rr.set_resources(dev, sg, probe)
@@ -418,7 +450,12 @@ def run(args):
                 exchange(r)                      # a denoising call is a frame of its own: its filter inputs travel, rank 0 filters
         if comms and not denoising:
             exchange(r)                          # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
-        if rank == 0:
+        if host_gather:
+            r.read_radiance_owned(shared["frame"])   # every rank: its own pixels into the one shared frame, over its own link
+            host_frame_barrier()                     # the frame is complete in host memory: the end of the §8d span
+            if rank == 0:
+                last["img"] = shared["frame"]
+        elif rank == 0:
             last["img"] = r.read_radiance(out=dst)   # blocking: the end of the §8d span
         else:
             r.synchronize()
@@ -430,7 +467,7 @@ def run(args):
     # N>1: rank 0 does more per frame than the others (unpack, resolve, the read-back): give it fewer tiles, so that its frame
     # takes as long as theirs.  Calibrated here on equal shares: c0 = what a frame costs beyond the slowest rank's tracing.
     calib = None
-    if world > 1:
+    if world > 1 and not host_gather:        # (the host-side gather gives rank 0 no extra work: equal shares)
         if args.root_weight:
             w0 = max(0, min(8, args.root_weight))
         else:
@@ -626,7 +663,10 @@ def run(args):
     shard_emulation = None
     if extras and world == 1 and not args.emulate_shard and not args.no_shard_emulation:
         shard_emulation = {"what": "ms per frame of rank 0's 1/N tile shard (32x8 tiles, tile id mod N) rendered alone on this GPU in the span form (reset_accumulation; %d x raytrace; "
-                                   "read_radiance of the frame buffer), median of 12 frames after 4 warm-up frames; no exchange; '1' = the whole frame, the same way" % SPP}
+                                   "read_radiance of the WHOLE frame buffer: what rank 0 of the RCCL-gather form pays), median of 12 frames after 4 warm-up frames; no exchange; '1' = the whole frame, the "
+                                   "same way.  ms_per_frame_host_gather: the same frames ended by lpt_renderer_read_radiance_owned — only the rank's own pixels travel to the (shared) host "
+                                   "frame, each GPU over its own PCIe link: the span of EVERY rank in the host-side-gather form (DESIGN 6), before the host barrier" % SPP}
+        dst_owned = dst if dst is not None else lp.pinned_array((HEIGHT, WIDTH, 4))
         for n_sh in (1, 2, 4, 8):
             rr = make_renderer(lanes=args.lanes or None, shard=n_sh)
             ts = []
@@ -640,6 +680,17 @@ def run(args):
                 rr.read_radiance(out=dst)
                 ts.append((time.perf_counter() - t1) * 1e3)
             ts = sorted(ts[4:])
+            th = []                                  # the same frames with the HOST-SIDE GATHER's read-back: only this rank's pixels travel
+            for k in range(12):
+                rr.synchronize()
+                t1 = time.perf_counter()
+                rr.reset_accumulation()
+                rr.accumulate = True
+                for _ in range(SPP):
+                    rr.raytrace(view)
+                rr.read_radiance_owned(dst_owned)
+                th.append((time.perf_counter() - t1) * 1e3)
+            th = sorted(th[2:])
             cc = rr.ray_counts()
             rr.enable_timings(True)
             rr.reset_accumulation()
@@ -649,9 +700,11 @@ def run(args):
             rr.synchronize()
             stg = {k: v[0] for k, v in rr.timings().items() if v[1]}
             rr.close()
-            shard_emulation[str(n_sh)] = {"ms_per_frame": ts[len(ts) // 2], "min_ms": ts[0], "rays_per_frame": (cc.closest + cc.shadow) / 16.0, "stage_ms": stg}
+            shard_emulation[str(n_sh)] = {"ms_per_frame": ts[len(ts) // 2], "min_ms": ts[0], "ms_per_frame_host_gather": th[len(th) // 2],
+                                          "rays_per_frame": (cc.closest + cc.shadow) / 28.0, "stage_ms": stg}
         for n_sh in (2, 4, 8):
             shard_emulation[str(n_sh)]["speedup_vs_1"] = shard_emulation["1"]["ms_per_frame"] / shard_emulation[str(n_sh)]["ms_per_frame"]
+            shard_emulation[str(n_sh)]["speedup_vs_1_host_gather"] = shard_emulation["1"]["ms_per_frame"] / shard_emulation[str(n_sh)]["ms_per_frame_host_gather"]
 
     # ================================================================== throughput: P renderers in flight, batched samples, no read-back
     throughput = None
@@ -706,6 +759,10 @@ def run(args):
         for rr in rs:
             rr.close()
 
+    host_gather_j = None
+    if host_gather:
+        host_gather_j = {"what": "no exchange on the GPUs: every rank wrote its owned pixels of the mean radiance into ONE shared-memory frame (lpt_renderer_read_radiance_owned), "
+                                 "a host-side barrier on shared words completed it", "frame_complete_on_rank0": frame_ok, "per_rank_rays": per_rank, "ranks": world}
     rccl = None
     if comms:
         rk, nr = comms[0].info()
@@ -756,6 +813,7 @@ def run(args):
             "readback": readback,
             "shard_emulation": shard_emulation,
             "rccl": rccl,
+            "host_gather": host_gather_j,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": rf_frac,
                          # the same launches against the bytes that actually crossed the fabric (replayed counter figure / this run's launch time): the
@@ -793,6 +851,14 @@ def run(args):
             out["cpu_baseline"] = None
     if use_dist:
         dist.barrier()
+    if shared is not None:
+        shared["frame"] = shared["words"] = None
+        lp.host_unregister(shared["whole"])
+        if rank == 0:
+            try:
+                os.unlink(shared["path"])
+            except OSError:
+                pass
     for c in comms:
         c.close()
     if use_dist:

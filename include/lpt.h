@@ -404,6 +404,17 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst);
  * renderer.rs:772-800, is such memory too).  Any lpt_device must exist first.  Free with lpt_host_free. */
 int lpt_host_alloc(size_t bytes, void **out);
 int lpt_host_free(void *ptr);
+/* new: page-lock and map caller-owned host memory for the device (hipHostRegister) — e.g. a POSIX shared-memory segment that every rank
+ * of a node maps, as the destination of lpt_renderer_read_radiance_owned.  Any lpt_device must exist first. */
+int lpt_host_register(void *ptr, size_t bytes);
+int lpt_host_unregister(void *ptr);
+/* new (multi-GPU, HOST-SIDE GATHER; no reference counterpart): this rank's OWNED pixels of the mean radiance written straight into
+ * `frame_dst`, a whole-frame w*h*4 float destination in page-locked host memory (lpt_host_alloc / lpt_host_register); the other ranks'
+ * pixels are not touched.  When the consumer of the frame is the host (the SURVEY 8d span ends in read_radiance) the ranks of a node can
+ * all write into ONE shared-memory frame — each GPU pushes its 1/N over its own PCIe link, nothing is gathered on rank 0's GPU first,
+ * and a host-side barrier completes the frame: the alternative to lpt_renderer_exchange + lpt_renderer_read_radiance on rank 0
+ * (DESIGN 6).  BlitMode::Pathtrace only.  Blocking. */
+int lpt_renderer_read_radiance_owned(lpt_renderer *r, float *frame_dst);
 /* replaces: renderer.queries.values()/labels()
  * (crates/standalone/src/gui/windows/performance_info.rs:19-20) */
 int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count);

@@ -121,6 +121,9 @@ SIGNATURES = {
     "lpt_renderer_get_submission_stats": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _pu32]),
     "lpt_host_alloc": (_i, [_sz, _pvp]),
     "lpt_host_free": (_i, [_vp]),
+    "lpt_host_register": (_i, [_vp, _sz]),
+    "lpt_host_unregister": (_i, [_vp]),
+    "lpt_renderer_read_radiance_owned": (_i, [_vp, _vp]),
     "lpt_renderer_reset_accumulation": (_i, [_vp]),
     "lpt_renderer_set_accumulate": (_i, [_vp, _i]),
     "lpt_renderer_get_accumulate": (_i, [_vp, C.POINTER(_i)]),

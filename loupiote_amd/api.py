@@ -415,6 +415,16 @@ class Renderer:
         _check(A.lib().lpt_renderer_read_radiance(self._h, A.ptr(out)))
         return out
 
+    def read_radiance_owned(self, out):
+        """host-side gather of a tile-sharded frame: this rank's OWNED pixels of the mean radiance straight into `out`, a whole-frame (h, w, 4)
+        float32 array in page-locked memory (`pinned_array`, or memory passed to `host_register` — a shared-memory frame every rank maps);
+        the other ranks' pixels are left alone"""
+        w, h = self.get_size()
+        if out.shape != (h, w, 4) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("read_radiance_owned: out must be a C-contiguous float32 array of shape (%d, %d, 4)" % (h, w))
+        _check(A.lib().lpt_renderer_read_radiance_owned(self._h, A.ptr(out)))
+        return out
+
     def read_denoiser(self):
         """current G-buffer / motion / accumulated radiance+variance / history of the ASVGF path"""
         w, h = self.get_size()
@@ -557,6 +567,15 @@ class _PinnedBlock:
                 self.ptr = None
         except Exception:
             pass
+
+
+def host_register(array):
+    """page-lock and map an existing C-contiguous numpy array (e.g. over a shared-memory segment) for the device: lpt_host_register"""
+    _check(A.lib().lpt_host_register(A.ptr(array), array.nbytes))
+
+
+def host_unregister(array):
+    _check(A.lib().lpt_host_unregister(A.ptr(array)))
 
 
 def pinned_array(shape, dtype=np.float32):

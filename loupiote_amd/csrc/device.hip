@@ -277,6 +277,8 @@ struct ReadPlan {
 };
 static int flush_pending(lpt_renderer *r, const ReadPlan *read = nullptr);
 static void forget_deferred_exchange(lpt_renderer *r);
+static FrameParams shard_params(const lpt_renderer *r);
+static inline uint32_t stream_grid(const lpt_renderer *r, size_t n);
 #define FLUSH_OR_RETURN(r) do { int fst__ = flush_pending(r); if (fst__ != LPT_OK) return fst__; } while (0)
 // Recorded raytrace() calls saw the scene / probe as it was when they were issued: an edit (or a destroy) submits them first.
 static int flush_device(lpt_device *dev) {
@@ -1981,6 +1983,39 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
+    return LPT_OK;
+}
+
+// Host-side gather of a tile-sharded frame: this rank's OWNED pixels (mean radiance) straight into `frame_dst`, a whole-frame destination in page-locked
+// host memory (lpt_host_alloc, or any memory passed to lpt_host_register — e.g. a shared-memory segment every rank of the node maps).  Pixels of other ranks
+// are not touched.  Blocking.
+int lpt_renderer_read_radiance_owned(lpt_renderer *r, float *frame_dst) {
+    if (!r || !frame_dst) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance_owned: null");
+    FLUSH_OR_RETURN(r);
+    if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
+    if (r->mode != LPT_BLIT_PATHTRACE) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance_owned: BlitMode::Pathtrace only (the denoising modes filter the whole frame on rank 0)");
+    HIP_TRY(hipSetDevice(r->dev->ordinal));
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, frame_dst, 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_read_radiance_owned: the destination must be page-locked host memory (lpt_host_alloc / lpt_host_register)");
+    }
+    const FrameParams p = shard_params(r);
+    if (p.n_slots) hipLaunchKernelGGL(k_resolve_owned, dim3(stream_grid(r, p.n_slots)), dim3(kBlock), 0, r->stream, p, r->accum, reinterpret_cast<float4 *>(mapped));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
+    return LPT_OK;
+}
+
+int lpt_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(LPT_ERR_INVALID_ARG, "lpt_host_register: null");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    return LPT_OK;
+}
+int lpt_host_unregister(void *ptr) {
+    if (!ptr) return LPT_OK;
+    HIP_TRY(hipHostUnregister(ptr));
     return LPT_OK;
 }
 

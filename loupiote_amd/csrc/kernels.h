@@ -1763,6 +1763,20 @@ __global__ __launch_bounds__(kBlock) void k_pack_owned(FrameParams p, const floa
         out[slot] = slot_to_pixel(p, slot, x, y) ? accum[(size_t)y * p.width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// HOST-SIDE GATHER: the rank's owned pixels of the MEAN radiance, written straight into a whole-frame destination — page-locked host memory
+// mapped into the device's address space (every rank of a node maps the same shared-memory frame).  Each GPU pushes its 1/N of the frame over its own
+// PCIe link, and nothing is gathered on rank 0's GPU first.  Pixels inside a tile are walked row by row here (32 x 16 B = 512-byte runs on the link).
+__global__ __launch_bounds__(kBlock) void k_resolve_owned(FrameParams p, const float4 *accum, float4 *dst) {
+    p.block8 = 0u;   // any enumeration of the owned pixels will do: row-major inside a tile
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < p.n_slots; slot += stride) {
+        uint32_t x, y;
+        if (!slot_to_pixel(p, slot, x, y)) continue;
+        const size_t px = (size_t)y * p.width + x;
+        const float4 a = accum[px];
+        dst[px] = a.w > 0.0f ? make_float4(a.x / a.w, a.y / a.w, a.z / a.w, 1.0f) : make_float4(0.f, 0.f, 0.f, 0.f);   // k_resolve's arithmetic
+    }
+}
 // first slot of rank `q` in the concatenation of all ranks' slot arrays: ranks own floor(n_tiles / world) tiles, the
 // first n_tiles % world of them one more (tile id mod world = owner)
 __device__ __host__ __forceinline__ uint32_t shard_slot_offset(uint32_t n_tiles, uint32_t world, uint32_t tile_area, uint32_t q) {

@@ -218,3 +218,42 @@ def test_sharded_frames_cut_into_runs_of_tiles_equal_one_gpu(device, cornell_glb
         r.close()
     pr.close()
     sg.close()
+
+
+@pytest.mark.parametrize("w,h,world,tile,weights", [(200, 120, 2, (32, 8), None), (203, 117, 3, (8, 8), None), (97, 61, 5, (16, 8), (1, 3, 2, 0, 2)), (203, 117, 8, (32, 8), None),
+                                                     (203, 117, 3, (64, 2), None)])
+def test_host_side_gather_every_rank_writes_its_own_pixels_into_one_frame(device, cornell_glb, w, h, world, tile, weights, tmp_path):
+    """the host-side gather: when the consumer of the frame is the host, every rank writes its OWNED pixels of the mean radiance straight into ONE
+    whole-frame destination in page-locked host memory (lpt_renderer_read_radiance_owned) — no exchange on the GPUs, each GPU's 1/N over its own link.  The
+    emulated ranks fill a frame that starts as NaN; it must equal the single-GPU read_radiance bit for bit, through lpt_host_alloc memory and through a
+    memory-mapped file registered with lpt_host_register (the shared-memory segment of a multi-process host)."""
+    sg, pr = _setup(device, cornell_glb)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    one = _renderer(device, sg, pr, w, h, 4)
+    ranks = [_renderer(device, sg, pr, w, h, 4, q, world, tile, weights) for q in range(world)]
+    frame = lp.pinned_array((h, w, 4))
+    shared = np.memmap(str(tmp_path / "frame.bin"), dtype=np.float32, mode="w+", shape=(h, w, 4))
+    lp.host_register(shared)
+    for k in range(2):
+        for _ in range(2):
+            one.raytrace(view)
+            for r in ranks:
+                r.raytrace(view)
+        want = one.read_radiance()
+        for dst in (frame, shared):
+            dst[...] = np.nan
+            for r in ranks:
+                r.read_radiance_owned(dst)
+            assert np.asarray(dst).tobytes() == want.tobytes(), (k, type(dst))
+    # a rank alone fills exactly its own pixels
+    frame[...] = np.nan
+    ranks[0].read_radiance_owned(frame)
+    filled = ~np.isnan(frame[..., 0])
+    assert filled.sum() > 0 and (world == 1 or not filled.all())
+    with pytest.raises(lp.Error):
+        ranks[0].read_radiance_owned(np.empty((h, w, 4), np.float32))     # pageable memory: refused, not silently staged
+    lp.host_unregister(shared)
+    for r in ranks + [one]:
+        r.close()
+    pr.close()
+    sg.close()

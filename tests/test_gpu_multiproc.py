@@ -77,6 +77,16 @@ def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processe
         assert 0 <= t2["rccl"]["tile_weights"][0] <= 8
 
 
+def test_host_side_gather_across_processes():
+    """`--exchange host`: no RCCL at all — the N processes write their owned pixels into ONE frame in POSIX shared memory (lpt_host_register +
+    lpt_renderer_read_radiance_owned) and a barrier on shared words completes it; the frame is the one-process frame bit for bit"""
+    one = _bench(["--no-extras"])
+    for n in (2, 3):
+        j = _bench(["--gpus", str(n), "--oversubscribe", "--exchange", "host", "--no-extras"])
+        assert j["n_gpus"] == n and j["rccl"] is None and j["host_gather"]["frame_complete_on_rank0"] is True and j["host_gather"]["ranks"] == n
+        assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"] and j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+
+
 def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):
     j = _bench(["--gpus", "2", "--oversubscribe", "--throughput", "--pipeline", "2"], {"LPT_RCCL_LIBRARY": fake_rccl})
     r = j["rccl"]
