@@ -89,3 +89,42 @@ def test_split_and_merged_traversal_launches_agree(device, cornell_glb):
     path, cp = T.render_hip(device, cornell_glb, 160, 96, 6, 3)
     assert merged.tobytes() == split.tobytes() == path.tobytes()
     assert (cm.closest, cm.shadow, cm.shaded) == (cs.closest, cs.shadow, cs.shaded) == (cp.closest, cp.shadow, cp.shaded)
+
+
+def test_stats_kernels_report_steps_per_ray_and_the_occluder_probe(device, cornell_glb):
+    """the stats variants of the per-bounce traversal launches (lpt_renderer_enable_stats): the steps-per-ray histogram covers every ray k_trace traced, its
+    maximum lies in the last non-empty bucket; the shadow rays that found an occluder and the occluder-cache probe's counts are consistent; the frame is unchanged"""
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    frames = []
+    for stats in (False, True):
+        r = lp.Renderer(device, (160, 96))
+        r.downsample_factor = 1.0
+        r.resize(device, sg, pr, (160, 96))
+        r.set_max_bounces(6)
+        r.set_vfov(T.VFOV)
+        r.set_option("path_rays", 0)          # the per-bounce launches (k_trace): the path kernel has no per-ray step counter
+        r.set_option("step_budget", 0)
+        r.enable_stats(stats)
+        r.reset_accumulation()
+        r.accumulate = True
+        r.reset_ray_counts()
+        r.raytrace_n(view, 3)
+        frames.append(r.read_radiance())
+        if stats:
+            c = r.ray_counts()
+            mx, hist = r.step_histogram()
+            assert int(hist.sum()) == c.closest + c.shadow - c.primary     # every ray k_trace carried (bounce 0 here is traced per ray as well: primary == 0)
+            last = max(k for k in range(12) if hist[k])
+            assert 2 ** last <= mx < 2 ** (last + 1) and mx >= 2
+            assert 0 < c.shadow_occluded < c.shadow
+            assert c.occluder_cache_hits <= c.occluder_cache_found <= c.shadow and c.occluder_cache_hits <= c.shadow_occluded
+            assert c.nodes > 0 and c.shadow_nodes > 0
+        r.close()
+    assert frames[0].tobytes() == frames[1].tobytes()
+    pr.close()
+    sg.close()
