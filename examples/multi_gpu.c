@@ -7,7 +7,8 @@
  *       RCCL id to LPT_ID_FILE, the others read it; lpt_comm_create (ncclCommInitRank); lpt_renderer_exchange per frame.
  *   otherwise                               -> all N ranks inside this process on device 0 (N sharded renderers,
  *       lpt_renderer_exchange_local): the single-process form, and how the example runs on a one-GPU box.
- * Rank 0 prints a checksum of the presented frame; it does not depend on N (the N-GPU image is the 1-GPU image bit for bit).
+ * Rank 0 prints a checksum of the presented frame; it does not depend on N (the N-GPU image is the 1-GPU image bit for bit) — and, in the
+ * single-process form, the checksum of the same frame assembled by the host-side gather (lpt_renderer_read_radiance_owned).
  * Build: gcc -std=c11 -Iinclude examples/multi_gpu.c -Lloupiote_amd -lloupiote_hip -Wl,-rpath,$PWD/loupiote_amd -lm -o multi_gpu */
 #include <math.h>
 #include <stdio.h>
@@ -82,8 +83,21 @@ int main(int argc, char **argv) {
         double sum = 0.0;
         size_t covered = 0;
         for (size_t i = 0; i < (size_t)W * H; ++i) { sum += img[4 * i] + img[4 * i + 1] + img[4 * i + 2]; covered += img[4 * i + 3] == 1.0f; }
-        printf("{\"ranks\": %d, \"multi_process\": %d, \"width\": %u, \"height\": %u, \"frames\": %d, \"covered\": %zu, \"checksum\": %.9g}\n",
-               world, multi_process, W, H, frames, covered, sum);
+        /* The HOST-SIDE GATHER, for hosts that consume the frame on the CPU: no exchange — every rank writes its OWNED pixels straight into one
+         * whole-frame buffer in page-locked host memory (in an N-process job: a shared-memory segment each process maps and passes to
+         * lpt_host_register), each GPU its 1/N over its own PCIe link; a barrier of the host's own completes the frame. */
+        double sum_owned = -1.0;
+        if (!multi_process) {
+            float *frame = NULL;
+            CHECK(lpt_host_alloc(sizeof(float) * 4 * (size_t)W * H, (void **)&frame));
+            for (size_t i = 0; i < 4 * (size_t)W * H; ++i) frame[i] = -1.0f;
+            for (int k = 0; k < n_local; ++k) CHECK(lpt_renderer_read_radiance_owned(r[k], frame));
+            sum_owned = 0.0;
+            for (size_t i = 0; i < (size_t)W * H; ++i) sum_owned += frame[4 * i] + frame[4 * i + 1] + frame[4 * i + 2];
+            CHECK(lpt_host_free(frame));
+        }
+        printf("{\"ranks\": %d, \"multi_process\": %d, \"width\": %u, \"height\": %u, \"frames\": %d, \"covered\": %zu, \"checksum\": %.9g, \"host_gather_checksum\": %.9g}\n",
+               world, multi_process, W, H, frames, covered, sum, sum_owned);
         free(img);
     }
     for (int k = 0; k < n_local; ++k) lpt_renderer_destroy(r[k]);

@@ -74,6 +74,7 @@ def test_plain_c_multi_gpu_example_gives_the_same_frame_for_any_rank_count(tmp_p
         assert p.returncode == 0, p.stderr
         j = json.loads(p.stdout.strip().splitlines()[-1])
         assert j["covered"] == 203 * 117 and j["ranks"] == n
+        assert j["host_gather_checksum"] == j["checksum"]      # every rank's own pixels written straight into one host frame: the same frame
         sums.append(j["checksum"])
     env = dict(os.environ, LPT_RANK="0", LPT_WORLD="1", LPT_ID_FILE=str(tmp_path / "rccl.id"))
     p = subprocess.run([exe, glb, "1", "203", "117", "3"], capture_output=True, text=True, timeout=300, env=env)
