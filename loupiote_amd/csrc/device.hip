@@ -1681,9 +1681,9 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
             const int launch_no = cb >= 0 ? cb : (int)nb;   // which strag_count[] this launch fills
             if (pipe) {
-                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
                 else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
-            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
             else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
             if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
                 const size_t clds = sizeof(uint32_t) * coop_stack_entries(r->sg->stats.max_depth);

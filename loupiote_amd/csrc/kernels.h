@@ -737,6 +737,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
     uint32_t n_occluded = 0, n_found = 0, n_would = 0;        // occluder-cache probe (STATS)
     uint32_t my_steps = 0;                                    // traversal steps of the ray in hand (STATS; the step budget)
+    uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2));   // STATS: 12 buckets + the maximum, behind the stacks (host: + 64 B)
+    if (STATS) { if (threadIdx.x < 16u) s_hist[threadIdx.x] = 0u; __syncthreads(); }
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
@@ -747,9 +749,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
             // results are written here, together with the refill, so that the emitter test / the deposit and
             // the stores run for a batch of lanes instead of once per finishing lane
             if (finished) {
-                if (STATS) {
-                    atomicMax(&ctr->max_steps, my_steps);
-                    atomicAdd(&ctr->step_hist[min(11, 31 - __clz((int)max(my_steps, 1u)))], 1u);
+                if (STATS) {   // the wave's own histogram in LDS (a global atomic per ray on a dozen hot words would take longer than the launch itself)
+                    atomicMax(&s_hist[12], my_steps);
+                    atomicAdd(&s_hist[min(11, 31 - __clz((int)max(my_steps, 1u)))], 1u);
                     my_steps = 0;
                 }
                 if (shadow) {
@@ -828,6 +830,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
         atomicAdd(&ctr->tris, (unsigned long long)n_tris);
         atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
         atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
+        __syncthreads();
+        if (lane < 12u && s_hist[lane]) atomicAdd(&ctr->step_hist[lane], s_hist[lane]);
+        if (lane == 12u) atomicMax(&ctr->max_steps, s_hist[12]);
         if (occ.table) {
             atomicAdd(&ctr->shadow_occluded, (unsigned long long)n_occluded);
             atomicAdd(&ctr->occ_found, (unsigned long long)n_found);
@@ -973,11 +978,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, 
         }
         __syncthreads();                // the stack is reused by the wave's next ray
     }
-    if (STATS && lane == 0) {
-        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
-        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
-        atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
-        atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
+    if (STATS && lane == 0) {   // most waves of the grid found no straggler: no atomic for them
+        if (n_nodes) atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+        if (n_tris) atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        if (s_nodes) atomicAdd(&ctr->shadow_nodes, (unsigned long long)s_nodes);
+        if (s_tris) atomicAdd(&ctr->shadow_tris, (unsigned long long)s_tris);
     }
 }
 

@@ -12,9 +12,9 @@ ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --emulate-shar
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -o p -- python3 $ARGS > $OUT/pmc1.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/pmc2 -o p -- python3 $ARGS > $OUT/pmc2.log 2>&1
-timeout 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr --output-format csv -d $OUT/pmc3 -o p -- python3 $ARGS > $OUT/pmc3.log 2>&1
+# (a third pass with TCP_* / TA_BUSY counters exceeds what the hardware collects in one pass on this pool: rocprofv3 aborts — left out)
 python3 tools/pmc_summary.py $(find $OUT/pmc* -name "*counter_collection.csv") > $OUT/pmc_summary.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-grep -E "k_path|k_trace|k_shade" $OUT/${TAG}_kernel_stats.csv | cut -c1-160
+grep -E "k_path|k_trace|k_shade" $OUT/${TAG}_kernel_stats.csv | sed "s/(lptd::DScene[^\"]*\"/\"/" | cut -c1-160
 grep -A14 "k_path\|k_trace<\|k_shade<" $OUT/pmc_summary.txt | head -120
 for f in $OUT/*.log; do grep -E 'rror|abort' $f | head -2; done
