@@ -118,6 +118,7 @@ def spawn_ranks(args):
             sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this node — cannot start %d ranks (one process per GPU)\n" % (n, have, n))
             return 3
     env_base = dict(os.environ)
+    env_base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's host driver only supports dmabuf IPC: without it RCCL fails across processes (hipIpcGetMemHandle)
     env_base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "LOCAL_WORLD_SIZE": str(n)})
     procs, logs = [], []
     tmp = tempfile.mkdtemp(prefix="lpt_bench_")
