@@ -202,6 +202,13 @@ impl Renderer {
         check(unsafe { ffi::lpt_renderer_read_radiance(self.h, out.as_mut_ptr()) })?;
         Ok(out)
     }
+    /// new (multi-GPU, host-side gather): this rank's OWNED pixels of the mean radiance straight into `frame`, a whole-frame buffer in
+    /// page-locked host memory (`HostFrame`, or memory passed to `ffi::lpt_host_register` — a shared-memory segment every rank maps);
+    /// the other ranks' pixels are left alone.  INTEGRATION.md §9.
+    pub fn read_radiance_owned(&mut self, frame: &mut HostFrame) -> Result<(), Error> {
+        assert!(frame.len >= (self.size.0 as usize) * (self.size.1 as usize) * 4);
+        check(unsafe { ffi::lpt_renderer_read_radiance_owned(self.h, frame.ptr) })
+    }
     /// `renderer.rs:551` without a swapchain: sRGB RGBA8 into the caller's rows
     pub fn blit_rgba8(&mut self, dst: &mut [u8], row_bytes: usize) -> Result<(), Error> {
         assert!(row_bytes >= (self.size.0 as usize) * 4 && dst.len() >= row_bytes * (self.size.1 as usize));
@@ -217,6 +224,18 @@ impl Renderer {
     pub fn exchange(&mut self, mode: i32) -> Result<(), Error> { check(unsafe { ffi::lpt_renderer_exchange(self.h, mode) }) }
 }
 impl Drop for Renderer { fn drop(&mut self) { unsafe { ffi::lpt_renderer_destroy(self.h); } } }
+
+/// page-locked host memory (`lpt_host_alloc`): a read-back destination the GPU writes by DMA or by zero-copy stores
+pub struct HostFrame { ptr: *mut f32, len: usize }
+impl HostFrame {
+    pub fn new(floats: usize) -> Result<Self, Error> {
+        let mut p: *mut std::os::raw::c_void = ptr::null_mut();
+        check(unsafe { ffi::lpt_host_alloc(floats * 4, &mut p) })?;
+        Ok(Self { ptr: p as *mut f32, len: floats })
+    }
+    pub fn as_slice(&self) -> &[f32] { unsafe { std::slice::from_raw_parts(self.ptr, self.len) } }
+}
+impl Drop for HostFrame { fn drop(&mut self) { unsafe { ffi::lpt_host_free(self.ptr as *mut _); } } }
 
 /// one rank of a node-wide frame (new functionality: the reference is single-GPU); RCCL lives inside the library
 pub struct Comm { h: *mut ffi::lpt_comm }
