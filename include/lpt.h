@@ -545,8 +545,10 @@ typedef enum lpt_option {
     LPT_OPT_STEP_BUDGET = 12,       /* per-bounce traversal launches: a ray not finished after this many steps is dropped by the per-lane kernel and traced
                                      * again by a whole wave (k_trace_coop: eight lanes per node), so that the one ray in 10^5 that needs hundreds of steps
                                      * does not set the duration of the launch; default 48, 0 = off */
-    LPT_OPT_BUDGET_RAYS = 13        /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
+    LPT_OPT_BUDGET_RAYS = 13,       /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
                                      * value applies the budget to every wavefront up to it) */
+    LPT_OPT_PACKET_QUADS = 14       /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
+                                     * (dense tiles, a multiple of four samples); 0 = always one sample of an 8x8-pixel patch */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

@@ -236,6 +236,7 @@ struct lpt_renderer {
     // per-bounce traversal launches: a ray that is not finished after this many steps is handed to k_trace_coop (a whole wave per ray); 0 = off.
     // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
+    bool packet_quads = true;      // a packet of bounce 0 = the four samples of a 4x4-pixel quarter (where the queue order allows it) instead of one sample of an 8x8 patch (LPT_OPT_PACKET_QUADS)
     uint32_t *occ_table = nullptr;   // occluder-cache probe (stats only): kOccEntries leaf slots + 1, zero = empty; allocated by enable_stats
     float occ_cell = 0.25f;          // its grid cell (scene units); LPT_OPT_OCC_CELL_MILLI
     void *default_probe = nullptr;
@@ -1417,6 +1418,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_OCC_CELL_MILLI: r->occ_cell = (float)std::min<uint64_t>(value, 1000000u) * 1.0e-3f; break;
     case LPT_OPT_STEP_BUDGET: r->step_budget = (uint32_t)std::min<uint64_t>(value, 1u << 20); break;
     case LPT_OPT_BUDGET_RAYS: r->budget_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_PACKET_QUADS: r->packet_quads = value != 0; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1437,6 +1439,7 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_OCC_CELL_MILLI: *value = (uint64_t)(r->occ_cell * 1000.0f + 0.5f); break;
     case LPT_OPT_STEP_BUDGET: *value = r->step_budget; break;
     case LPT_OPT_BUDGET_RAYS: *value = r->budget_rays; break;
+    case LPT_OPT_PACKET_QUADS: *value = r->packet_quads; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1698,8 +1701,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 stage_begin(r, ST_PRIMARY, s);
                 const uint32_t packets = div_up(n_rays, 64u);
                 const size_t plds = (size_t)(48u + 7u * r->sg->stats.max_depth + 8u) * sizeof(uint32_t);   // 48 planes + the stack
-                if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
-                else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0);
+                // 4 samples of a 4x4-pixel quarter per packet instead of one sample of an 8x8 patch, where the queue order allows it: a dense frame
+                // (queue index = sample * slots + slot), 8x8 pixel blocks inside the tiles, whole blocks, a multiple of four samples
+                const uint32_t quad_slots = (r->packet_quads && dense && p.block8 && p.n_slots % 64u == 0u && p.slot0 % 64u == 0u && n_samples % 4u == 0u) ? p.n_slots : 0u;
+                if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
+                else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 stage_end(r, s);
             } else if (!(r->path_rays && n_rays <= r->path_rays)) trace(0, -1);   // a path-kernel wavefront traces its primary rays itself
         }

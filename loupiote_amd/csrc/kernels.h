@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, f
 // 8x8 packet enters 17.5 nodes and tests 11.7 triangles where ONE of its rays alone enters 14.9 and tests 3.6 (tools/dev/packet_probe.cpp).
 // The wave's stack (node indices) is one LDS column per wave.  Works for any rays; it only pays for coherent ones.
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce) {
+__global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, uint32_t quad_slots) {
     // LDS of the wave: the 48 child planes of the node in hand as floats (192 B), then the stack of node indices — 7 siblings per
     // level + the path: (7 * depth + 8) entries (host).  ONE wave per block: the hand-overs through `planes` and `stk` below are
     // ordered by the wave's own program order (LDS operations of a wave complete in order) plus the barriers that keep the compiler
@@ -1030,7 +1030,19 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
     const uint32_t lane = threadIdx.x;
     uint32_t visits = 0, tests = 0;
     for (uint32_t base = blockIdx.x * 64u; base < count; base += gridDim.x * 64u) {
-        const uint32_t ray = base + lane;
+        // Which 64 rays form the packet.  Queue order (a dense frame): sample k's rays at k * quad_slots + slot, 64 consecutive slots = an 8x8-pixel patch.
+        // quad_slots != 0 (4 samples per pixel, or a multiple): the packet is the FOUR samples of a 4x4-pixel quarter of that patch instead — the same 64 rays per
+        // four packets, but a footprint half as wide: 16.3 nodes and 7.4 triangles per packet instead of 17.7 and 12.1 (tools/dev/packet_probe.cpp).
+        uint32_t ray = base + lane;
+        if (quad_slots) {
+            const uint32_t pk = base >> 6;                      // packet number: (sample group, 8x8 block, quarter)
+            const uint32_t blocks = quad_slots >> 6;            // 8x8 blocks per sample
+            const uint32_t grp = pk / (blocks * 4u), rem = pk - grp * (blocks * 4u);
+            const uint32_t blk = rem >> 2, qtr = rem & 3u;
+            const uint32_t smp = grp * 4u + (lane >> 4), sub = lane & 15u;
+            const uint32_t px = (qtr & 1u) * 4u + (sub & 3u), py = (qtr >> 1) * 4u + (sub >> 2);
+            ray = smp * quad_slots + blk * 64u + py * 8u + px;
+        }
         const bool live = ray < count;
         f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
         if (live) { const float4 o4 = q.o[ray], d4 = q.d[ray]; o = mk3(o4.x, o4.y, o4.z); d = mk3(d4.x, d4.y, d4.z); }

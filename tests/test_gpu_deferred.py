@@ -260,12 +260,12 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
     """The default for a frame this small: bounce 0 per ray (packet traversal, k_trace_packet: one tree walk per 8x8-pixel patch, is chosen by pixel
     footprint — packet_primary = 1 forces it), then every later bounce in ONE launch (k_path); path_rays = 0 selects the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace, one
     memory round trip per traversal step: ray_step_pipe), pipe_rays = 0 their two-round-trip step, packet_primary = 0 per-ray traversal
-    for bounce 0 too, merge_trace = 0 the split k_intersect / k_shadow launches.  The order of the tests differs, the frame and the ray
+    for bounce 0 too, packet_quads = 0 packets of one sample over 8x8 pixels instead of four samples over 4x4, merge_trace = 0 the split k_intersect / k_shadow launches.  The order of the tests differs, the frame and the ray
     counts do not (lpt_renderer_set_option: no environment variable selects a kernel)."""
     _, sg, pr = cornell
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
-    variants = ({}, {"packet_primary": 1}, {"path_rays": 0}, {"path_rays": 0, "packet_primary": 1}, {"path_rays": 0, "pipe_rays": 0, "packet_primary": 1},
+    variants = ({}, {"packet_primary": 1}, {"packet_primary": 1, "packet_quads": 0}, {"path_rays": 0}, {"path_rays": 0, "packet_primary": 1}, {"path_rays": 0, "pipe_rays": 0, "packet_primary": 1},
                 {"path_rays": 0, "pipe_rays": 30000}, {"merge_trace": 0}, {"packet_primary": 0}, {"packet_primary": 0, "pipe_rays": 0},
                 {"path_waves_per_cu": 3, "path_refill": 20, "packet_primary": 1}, {"path_refill": 63}, {"path_refill": 0},
                 # the step budget: rays not finished after n steps are dropped by the per-lane kernel and traced again by a whole wave (k_trace_coop);
