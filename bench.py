@@ -614,7 +614,7 @@ def run(args):
     if pk_launches:
         pk_avg = pk_ms / pk_launches
         pk_bytes = 32.0 * 64 + 16.0 * 64 + pk_nodes * accel.node_bytes + pk_tris * accel.tri_bytes      # per packet: 64 rays read, 64 hits written, the nodes / triangles once
-        packet_j = {"kernel": "k_trace_packet", "what": "bounce 0: one tree walk per 64 coherent primary rays (an 8x8-pixel patch of one sample), node and triangle fetches by scalar loads",
+        packet_j = {"kernel": "k_trace_packet", "what": "bounce 0: one tree walk per 64 coherent primary rays (the four samples of a 4x4-pixel patch), node and triangle fetches by scalar loads",
                     "avg_launch_ms": pk_avg, "launches": pk_launches, "rays_per_launch": sc_.primary / pk_launches, "Mrays_per_s": sc_.primary / pk_launches / (pk_avg * 1e-3) / 1e6,
                     "nodes_per_packet": pk_nodes, "tris_per_packet": pk_tris, "bytes_per_packet": pk_bytes,
                     "achieved_GBps": sc_.primary / 64.0 / pk_launches * pk_bytes / (pk_avg * 1e-3) / 1e9}

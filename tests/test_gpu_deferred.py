@@ -284,3 +284,21 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
         # which kernel traced bounce 0: packets only where asked for — the default (2) picks by pixel footprint, and a frame this small is traced per ray
         assert c.primary == (4 * W * H if packet == 1 and "merge_trace" not in opts else 0), opts
         r.close()
+
+
+@pytest.mark.parametrize("samples", [4, 8, 12, 6])
+def test_packets_of_four_samples_on_a_dense_frame(device, cornell, cornell_glb, samples):
+    """k_trace_packet on a frame of whole 32x8 tiles (the 203x117 frames above are not): with a multiple of four samples in the wavefront a packet is the
+    four samples of a 4x4-pixel quarter of an 8x8 patch (LPT_OPT_PACKET_QUADS, default), else — 6 samples, or the option off — one sample of the whole patch.
+    Which 64 rays share a tree walk changes nothing: the frame is the oracle's, the primary rays are all traced by packets."""
+    _, sg, pr = cornell
+    size = (256, 136)
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    ref, oc = harness.render_oracle(cornell_glb, size[0], size[1], DEPTH, samples)
+    for quads in (1, 0):
+        r = _renderer(device, sg, pr, 0, size=size, options={"packet_primary": 1, "packet_quads": quads})
+        r.raytrace_n(view, samples)
+        assert r.read_radiance().tobytes() == ref.tobytes(), (samples, quads)
+        c = r.ray_counts()
+        assert (c.closest, c.shadow, c.shaded, c.primary) == (oc.closest, oc.shadow, oc.shaded, samples * size[0] * size[1]), (samples, quads)
+        r.close()
