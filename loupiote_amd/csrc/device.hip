@@ -1642,7 +1642,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
         // the one-round-trip step (kernels.h ray_step_pipe): 78 VGPRs, so 6 waves per SIMD instead of 8, ~3 % more nodes and ~12 % more
         // triangles fetched per ray — and still 1 % less time per frame at 8 M rays, 2 % for a 1 M-ray tile shard
-        // (profiles/r03_experiments_ab.txt); LPT_PIPE_RAYS=0 selects the two-round-trip step
+        // (profiles/r03_experiments_ab.txt); LPT_OPT_PIPE_RAYS 0 selects the two-round-trip step
         const bool pipe = n_rays <= r->pipe_rays;
         // persistent waves: about 2.5 primary rays per lane, between 8 waves per CU and all that fit (24 at 78 VGPRs, 32 at 59).  A 1/8
         // tile shard (1 M rays per launch) is best at 24 either way (round 3, span form, two-round-trip step: 8 / 12 / 16 / 24 / 32
@@ -1672,7 +1672,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         uint32_t seed = seed0;
         // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
         // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
-        // instead of 2*nb; split (LPT_MERGE_TRACE=0): IntersectorPass and the shadow pass as separate launches.
+        // instead of 2*nb; split (LPT_OPT_MERGE_TRACE 0): IntersectorPass and the shadow pass as separate launches.
         // the occluder-cache probe rides with the stats kernels only (kernels.h OccProbe); its table belongs to the renderer
         OccProbe occ{nullptr, 0u, 0.0f};
         if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
