@@ -1058,12 +1058,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q
         uint32_t node_index = 0;
         bool have = true;
         while (have) {
+            // the 48 quantised planes are the same for every lane: lane j fetches and converts plane j — ONE conversion instruction for the wave
+            // instead of 48 — and LDS hands each lane the ones it needs (its near and far plane per axis, four children per read).  The fetch is issued
+            // BEFORE the header's scalar loads (which wait for themselves only): the two round trips overlap
+            const uint32_t plane_byte = reinterpret_cast<const uint8_t *>(nodes + node_index)[32u + (lane < 48u ? lane : lane - 48u)];   // every lane: no branch around the load
             uint4 n0, n1;
             sload_node_header(nodes + node_index, n0, n1);   // wave-uniform address
-            // the 48 quantised planes are the same for every lane: lane j converts plane j — ONE conversion instruction for the wave
-            // instead of 48 — and LDS hands each lane the ones it needs (its near and far plane per axis, four children per read)
             __syncthreads();   // the previous node's plane reads are done before its planes are overwritten (one wave: no wait, a compiler fence)
-            if (lane < 48u) planes[lane] = (float)reinterpret_cast<const uint8_t *>(nodes + node_index)[32u + lane];
+            if (lane < 48u) planes[lane] = (float)plane_byte;
             __syncthreads();
             if (STATS) visits++;
             const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
