@@ -61,6 +61,24 @@ def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
         assert j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
 
 
+def test_the_drivers_launcher_command_line(fake_rccl):
+    """the contract's N>1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` —
+    the ranks come from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), bench.py starts none itself; rank 0 prints the one JSON line"""
+    one = _bench(["--no-extras"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LPT_RCCL_LIBRARY"] = fake_rccl
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--root-weight", "8", "--no-extras"] + SMALL
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines            # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl"]["rccl_nranks"] == 2 and j["rccl"]["exchange_frame_complete_on_rank0"] is True
+    assert j["scaling"] == "strong" or j["scaling"] == "weak"
+    assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
+
+
 def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processes(fake_rccl):
     """(i) every exchange inside lpt_comm_group_begin / _end: the stand-in enqueues grouped operations only at the outermost ncclGroupEnd,
     so a second phase (unpack) enqueued too early would read stale tiles and the checksum would differ.  (ii) BlitMode::Temporal across two
