@@ -556,6 +556,9 @@ def run(args):
         img = last["img"]
         frame_ok = bool(np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img)) and float(img[..., :3].mean()) > 0.0)
         checksum = float(np.float64(img[..., :3].sum()))
+    if host_gather:
+        # `img` IS the shared frame: no rank may start the next frame (the stats frame below writes its pixels into it) before rank 0 has read this one
+        dist.barrier()
 
     # ---- roofline of the dominant kernel (k_trace), this rank: algorithmic bytes per launch
     # = closest rays * (32 B ray read + 16 B hit write + N*80 B nodes + T*48 B triangles)

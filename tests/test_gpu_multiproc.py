@@ -67,7 +67,11 @@ def test_the_drivers_launcher_command_line(fake_rccl):
     one = _bench(["--no-extras"])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["LPT_RCCL_LIBRARY"] = fake_rccl
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+    import socket
+    with socket.socket() as sk:      # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--root-weight", "8", "--no-extras"] + SMALL
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
