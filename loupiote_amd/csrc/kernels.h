@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, f
 // 8x8 packet enters 17.5 nodes and tests 11.7 triangles where ONE of its rays alone enters 14.9 and tests 3.6 (tools/dev/packet_probe.cpp).
 // The wave's stack (node indices) is one LDS column per wave.  Works for any rays; it only pays for coherent ones.
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, uint32_t quad_slots) {
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8))) void k_trace_packet(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, uint32_t quad_slots) {
     // LDS of the wave: the 48 child planes of the node in hand as floats (192 B), then the stack of node indices — 7 siblings per
     // level + the path: (7 * depth + 8) entries (host).  ONE wave per block: the hand-overs through `planes` and `stk` below are
     // ordered by the wave's own program order (LDS operations of a wave complete in order) plus the barriers that keep the compiler
