@@ -547,8 +547,20 @@ typedef enum lpt_option {
                                      * does not set the duration of the launch; default 48, 0 = off */
     LPT_OPT_BUDGET_RAYS = 13,       /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
                                      * value applies the budget to every wavefront up to it) */
-    LPT_OPT_PACKET_QUADS = 14       /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
+    LPT_OPT_PACKET_QUADS = 14,      /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
                                      * (dense tiles, a multiple of four samples); 0 = always one sample of an 8x8-pixel patch */
+    LPT_OPT_POOL_RAYS = 15,         /* wavefronts of more than LPT_OPT_PATH_RAYS and at most this many rays run every bounce behind the primary hits in ONE
+                                     * launch as a CU-local POOL of trace and shade work (k_pool, round 5): a path is a record that the waves of a block
+                                     * hand to each other through rings in LDS — any wave's idle lanes take the next ray to trace, a wave without rays in
+                                     * flight shades 64 hits of one kind with all its lanes; no chip-wide barrier per bounce (renderer.rs:484-509) and no
+                                     * lane that waits for its own wave's shading batch.  0: never */
+    LPT_OPT_POOL_SHADERS = 16,      /* pool kernel: waves of a block that prefer shading to tracing (default 2) */
+    LPT_OPT_POOL_ENTRIES = 17,      /* pool kernel: path records per block, a power of two in 256..32768 (default 4096) */
+    LPT_OPT_POOL_WAVES = 18,        /* pool kernel: waves per block, 4 / 8 / 16 (default 16: one block per CU) */
+    LPT_OPT_POOL_REFILL = 19,       /* pool kernel: lanes tracing at or below which a wave retires its finished rays and refills (default 44) */
+    LPT_OPT_SPLIT_RAYS = 20,        /* a batch above this many rays that would still fit one wavefront leaves as two, on the renderer's lanes (default
+                                     * 3 000 000; 0: never split below LPT_OPT_WAVEFRONT_RAYS) */
+    LPT_OPT_BUDGET_SPLIT = 21       /* 1: the step budget also applies to the pieces of a cut batch (default 0: only to submissions that leave as one wavefront) */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "build_kernels.h"
+#include "pool_kernels.h"
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 
@@ -158,6 +159,8 @@ struct Wavefront {
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr;
     uint32_t *strag = nullptr;      // the stragglers of a traversal launch (k_trace's step budget -> k_trace_coop): ray index | shadow << 31
+    float4 *pool_slab = nullptr;    // k_pool's path records: blocks x entries x kPoolRec (allocated by the first wavefront that takes the pool kernel)
+    size_t pool_slab_elems = 0;
     FrameCounters *ctr = nullptr;
     size_t ray_cap = 0;             // rays (pixel slots x samples) the per-ray buffers can hold; 0 = not allocated yet
     hipEvent_t done = nullptr;      // recorded on `stream` behind the lane's last traversal / shading launch
@@ -169,7 +172,8 @@ constexpr uint32_t kStepBudget = 48u, kBudgetRays = 3000000u;  // defaults of LP
 constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to this angle per pixel (measured: 1.53 mrad, 960x540: packets 4.46 against 4.51 ms; 2.05 mrad, 720x405: 3.32 against 3.20)
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 450000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over against the per-bounce launches WITH their step budget
-constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts
+constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
+constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
 struct lpt_renderer {
@@ -236,6 +240,12 @@ struct lpt_renderer {
     // per-bounce traversal launches: a ray that is not finished after this many steps is handed to k_trace_coop (a whole wave per ray); 0 = off.
     // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
+    bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
+    uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
+    // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
+    uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 4096u, pool_waves = 16u;
+    int pool_refill = 44;
+    uint32_t *err_host = nullptr, *err_dev = nullptr;   // the device's error word: one page-locked host word the kernels write (a bounded wait that ran out), checked behind every blocking call
     bool packet_quads = true;      // a packet of bounce 0 = the four samples of a 4x4-pixel quarter (where the queue order allows it) instead of one sample of an 8x8 patch (LPT_OPT_PACKET_QUADS)
     uint32_t *occ_table = nullptr;   // occluder-cache probe (stats only): kOccEntries leaf slots + 1, zero = empty; allocated by enable_stats
     float occ_cell = 0.25f;          // its grid cell (scene units); LPT_OPT_OCC_CELL_MILLI
@@ -293,6 +303,15 @@ static int flush_device(lpt_device *dev) {
 }
 // what read_radiance / read_pixels / blit show: the exchanged whole frame after lpt_renderer_exchange, else the local target
 static inline const float4 *presented_target(const lpt_renderer *r) { return (r->presented && r->frame) ? r->frame : r->accum; }
+// The device's error word (a page-locked host word the kernels write when a bounded wait runs out: k_pool's ring locks and idle waits).  Read behind a
+// blocking call, once the stream has been waited for: the frame that raised it is void.
+static int check_device_error(lpt_renderer *r) {
+    if (!r->err_host) return LPT_OK;
+    const uint32_t code = *(volatile uint32_t *)r->err_host;
+    if (!code) return LPT_OK;
+    *(volatile uint32_t *)r->err_host = 0u;
+    return fail(LPT_ERR_HIP, "a device-side bounded wait ran out (code 0x%x): the frame is void", code);
+}
 static inline size_t stack_bytes(const DScene &sc) { return (size_t)sc.stack_entries * kTraceBlock * sizeof(uint2); }
 
 template <typename T>
@@ -1029,6 +1048,9 @@ static void free_ray_buffers(Wavefront &wf) {
     wf.q[0] = Queue{}; wf.q[1] = Queue{}; wf.sq = ShadowQueue{};
     wf.hits = wf.Lsum = nullptr;
     wf.strag = nullptr;
+    if (wf.pool_slab) hipFree(wf.pool_slab);
+    wf.pool_slab = nullptr;
+    wf.pool_slab_elems = 0;
     wf.ray_cap = 0;
 }
 
@@ -1184,6 +1206,8 @@ int lpt_renderer_create(lpt_device *dev, uint32_t width, uint32_t height, lpt_re
     r->h = (uint32_t)((float)height * r->downsample);
     hipError_t e = hipMalloc(&r->totals, sizeof(Totals));
     if (e == hipSuccess) e = hipMemset(r->totals, 0, sizeof(Totals));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&r->err_host, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) { *r->err_host = 0u; e = hipHostGetDevicePointer((void **)&r->err_dev, r->err_host, 0); }
     if (e == hipSuccess) e = hipMalloc(&r->default_probe, 4);
     if (e == hipSuccess) e = hipMemset(r->default_probe, 0, 4);  // 1x1 zero texel: black environment (device.rs:13-26)
     if (e == hipSuccess) e = hipMalloc(&r->srgb_thr, 256 * sizeof(float));
@@ -1229,6 +1253,7 @@ int lpt_renderer_destroy(lpt_renderer *r) {
         if (wf.ctr) hipFree(wf.ctr);
     }
     if (r->totals) hipFree(r->totals);
+    if (r->err_host) hipHostFree(r->err_host);
     if (r->occ_table) hipFree(r->occ_table);
     if (r->d_table) hipFree(r->d_table);
     if (r->default_probe) hipFree(r->default_probe);
@@ -1419,6 +1444,13 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_STEP_BUDGET: r->step_budget = (uint32_t)std::min<uint64_t>(value, 1u << 20); break;
     case LPT_OPT_BUDGET_RAYS: r->budget_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_PACKET_QUADS: r->packet_quads = value != 0; break;
+    case LPT_OPT_POOL_RAYS: r->pool_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_POOL_SHADERS: if (value > 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_SHADERS: 0..16"); r->pool_shaders = (uint32_t)value; break;
+    case LPT_OPT_POOL_ENTRIES: if (value < 256u || value > 32768u || (value & (value - 1u))) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_ENTRIES: a power of two in 256..32768"); r->pool_entries = (uint32_t)value; break;
+    case LPT_OPT_POOL_WAVES: if (value != 4u && value != 8u && value != 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_WAVES: 4, 8 or 16"); r->pool_waves = (uint32_t)value; break;
+    case LPT_OPT_POOL_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_REFILL: 0..63"); r->pool_refill = (int)value; break;
+    case LPT_OPT_SPLIT_RAYS: r->split_rays = value; break;
+    case LPT_OPT_BUDGET_SPLIT: r->budget_split = value != 0; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1440,6 +1472,13 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_STEP_BUDGET: *value = r->step_budget; break;
     case LPT_OPT_BUDGET_RAYS: *value = r->budget_rays; break;
     case LPT_OPT_PACKET_QUADS: *value = r->packet_quads; break;
+    case LPT_OPT_POOL_RAYS: *value = r->pool_rays; break;
+    case LPT_OPT_POOL_SHADERS: *value = r->pool_shaders; break;
+    case LPT_OPT_POOL_ENTRIES: *value = r->pool_entries; break;
+    case LPT_OPT_POOL_WAVES: *value = r->pool_waves; break;
+    case LPT_OPT_POOL_REFILL: *value = (uint64_t)r->pool_refill; break;
+    case LPT_OPT_SPLIT_RAYS: *value = r->split_rays; break;
+    case LPT_OPT_BUDGET_SPLIT: *value = r->budget_split; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1678,7 +1717,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
         // the step budget pays where nothing else fills the tail of a launch: a submission that is ONE wavefront (a tile shard, a small frame).  The
         // pieces of a cut batch overlap on the renderer's lanes and hide each other's tails: 1/2 shard as two wavefronts 6.84 ms without, 6.93 with it
-        const uint32_t budget = (r->step_budget && (solo || r->budget_rays > kBudgetRays) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
+        const uint32_t budget = (r->step_budget && (solo || r->budget_split) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
@@ -1695,6 +1734,10 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             }
             stage_end(r, s);
         };
+        // The pool kernel (pool_kernels.h) for wavefronts above the path kernel's range: one block of pool_waves waves per 16 wave slots of a CU, its LDS
+        // (traversal stacks of every wave + the rings) must fit the CU's 160 KB — a tree too deep for that takes the per-bounce launches
+        const uint32_t pool_lds = pool_lds_bytes(sc.stack_entries, r->pool_waves, r->pool_entries);
+        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && pool_lds <= 160u * 1024u;
         if (r->merge_trace) {
             if (packet) {
                 // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
@@ -1707,7 +1750,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 stage_end(r, s);
-            } else if (!(r->path_rays && n_rays <= r->path_rays)) trace(0, -1);   // a path-kernel wavefront traces its primary rays itself
+            } else if (!(r->path_rays && n_rays <= r->path_rays) && !use_pool) trace(0, -1);   // a path- or pool-kernel wavefront traces its primary rays itself
         }
         // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
         // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
@@ -1723,7 +1766,36 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             else hipLaunchKernelGGL((k_path<false, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
             stage_end(r, s);
         }
-        for (uint32_t b = 0; b < nb && !path; ++b) {
+        if (use_pool) {
+            stage_begin(r, ST_PATH, s);
+            const uint32_t blocks = cus * (16u / r->pool_waves);
+            const size_t need = (size_t)blocks * r->pool_entries * kPoolRec;
+            if (wf.pool_slab_elems < need) {
+                HIP_TRY(hipStreamSynchronize(s));
+                if (wf.pool_slab) HIP_TRY(hipFree(wf.pool_slab));
+                wf.pool_slab = nullptr; wf.pool_slab_elems = 0;
+                HIP_TRY(hipMalloc(&wf.pool_slab, sizeof(float4) * need));
+                wf.pool_slab_elems = need;
+            }
+            PoolArgs pa{wf.pool_slab, r->pool_entries, std::min(r->pool_shaders, r->pool_waves), r->pool_refill, 256u, r->err_dev};
+            const float4 *h0 = packet ? wf.hits : (const float4 *)nullptr;
+            static bool attr_set = false;
+            if (!attr_set) {   // more than 64 KB of dynamic LDS needs the attribute
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            const dim3 pg(blocks), pb(64u * r->pool_waves);
+            if (denoise) {
+                if (r->stats) hipLaunchKernelGGL((k_pool<true, true>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
+                else hipLaunchKernelGGL((k_pool<true, false>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
+            } else if (r->stats) hipLaunchKernelGGL((k_pool<false, true>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
+            else hipLaunchKernelGGL((k_pool<false, false>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
+            stage_end(r, s);
+        }
+        for (uint32_t b = 0; b < nb && !path && !use_pool; ++b) {
             seed += 1u;                          // :453, :487
             const Queue qin = wf.q[b & 1u], qout = wf.q[(b + 1u) & 1u];
             if (!r->merge_trace) {
@@ -1829,7 +1901,7 @@ static int flush_pending(lpt_renderer *r, const ReadPlan *read) {
     // ... and a batch of more than 3 M rays that would still fit one wavefront leaves as TWO (on the renderer's two lanes): a 1/2 shard of the headline frame
     // (4.15 M rays) 7.22 -> 6.81 ms; below that the halves are too small to hide each other's drains (a 1/4 shard, 2 x 1.04 M: 4.62 -> 4.75 ms; profiles/r04_experiments_ab.txt E)
     const uint64_t total = (uint64_t)n_slots * b.n;
-    if (!r->max_fused && r->mode == LPT_BLIT_PATHTRACE && granules > 1u && (total > r->wavefront_rays || (total > kSplitRays && r->wavefront_rays >= kSplitRays && r->n_lanes > 1))) {
+    if (!r->max_fused && r->mode == LPT_BLIT_PATHTRACE && granules > 1u && (total > r->wavefront_rays || (r->split_rays && total > r->split_rays && r->n_lanes > 1))) {
         const uint64_t fit = r->wavefront_rays / ((uint64_t)granule * b.n);           // granules of b.n samples in about 4 M rays
         const uint32_t pieces = std::max(2u, div_up(granules, (uint32_t)std::max<uint64_t>(fit, 1u)));
         per_piece = div_up(granules, pieces);                     // the same number of pieces, evened out
@@ -1956,7 +2028,7 @@ int lpt_renderer_synchronize(lpt_renderer *r) {
     FLUSH_OR_RETURN(r);
     HIP_TRY(hipSetDevice(r->dev->ordinal));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return LPT_OK;
+    return check_device_error(r);
 }
 
 int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes) {
@@ -1979,7 +2051,7 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
         if (st != LPT_OK) return st;
         const hipError_t se = hipStreamSynchronize(r->stream);
         if (se != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(se));
-        return LPT_OK;
+        return check_device_error(r);
     }
     FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
@@ -1989,7 +2061,7 @@ int lpt_renderer_read_radiance(lpt_renderer *r, float *dst) {
     if (e == hipSuccess) e = hipMemcpyAsync(dst, r->scratch, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, r->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
-    return LPT_OK;
+    return check_device_error(r);
 }
 
 // Host-side gather of a tile-sharded frame: this rank's OWNED pixels (mean radiance) straight into `frame_dst`, a whole-frame destination in page-locked
@@ -2011,7 +2083,7 @@ int lpt_renderer_read_radiance_owned(lpt_renderer *r, float *frame_dst) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
-    return LPT_OK;
+    return check_device_error(r);
 }
 
 int lpt_host_register(void *ptr, size_t bytes) {
@@ -2045,7 +2117,7 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
         if (st != LPT_OK) return st;
         const hipError_t se = hipStreamSynchronize(r->stream);
         if (se != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(se));
-        return LPT_OK;
+        return check_device_error(r);
     }
     FLUSH_OR_RETURN(r);
     if (!r->accum) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: no render target");
@@ -2062,7 +2134,7 @@ int lpt_renderer_blit_rgba8(lpt_renderer *r, uint8_t *dst, size_t row_bytes) {
     if (e == hipSuccess) e = hipMemcpy2DAsync(dst, row_bytes, r->scratch, (size_t)r->w * 4, (size_t)r->w * 4, r->h, hipMemcpyDeviceToHost, r->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     if (e != hipSuccess) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: %s", hipGetErrorString(e));
-    return LPT_OK;
+    return check_device_error(r);
 }
 
 int lpt_renderer_read_pixels(lpt_renderer *r, uint8_t *dst) {
@@ -2128,7 +2200,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     out->wave_steps = t.wave_steps; out->live_lanes = t.live_lanes; out->node_lanes = t.node_lanes; out->tri_lanes = t.tri_lanes;
     out->primary = t.primary; out->packet_nodes = t.packet_nodes; out->packet_tris = t.packet_tris;
     out->shadow_occluded = t.shadow_occluded; out->occluder_cache_found = t.occ_found; out->occluder_cache_hits = t.occ_hits;
-    return LPT_OK;
+    return check_device_error(r);
 }
 
 int lpt_renderer_reset_ray_counts(lpt_renderer *r) {

@@ -80,6 +80,9 @@ struct FrameCounters {
     uint32_t strag_count[kMaxBounces + 1];
     uint32_t phead[8 * 32];       // k_path's own chunk heads over the bounce-0 queue (ihead[0] may have been drained by a per-ray bounce-0 launch)
     uint32_t shaded[kMaxBounces];
+    // k_shade's surface-hit counts: ONE atomic per block and launch, spread over 8 words per bounce on separate 128-byte lines (one atomic per WAVE on
+    // shaded[bounce] — 4096 of them on one word, all in the last microseconds of a launch — was the floor of a shard-sized shading launch: DESIGN §5.2)
+    uint32_t shaded_part[kMaxBounces * 8 * 32];
     unsigned long long nodes, tris, shadow_nodes, shadow_tris;
     unsigned long long wave_steps, live_lanes, node_lanes, tri_lanes;  // closest-hit kernel, stats only
     unsigned long long packet_nodes, packet_tris;   // k_trace_packet, stats only: nodes entered / triangles tested per PACKET, summed
@@ -1619,9 +1622,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
         }
         n_surface += so.is_surface ? 1u : 0u;
     }
-    // surface-hit count: wave reduce, one atomic per wave per LAUNCH
+    // surface-hit count: wave reduce, block reduce through LDS, ONE atomic per block and launch on one of 8 words (FrameCounters::shaded_part)
     for (int off = 32; off > 0; off >>= 1) n_surface += __shfl_down(n_surface, off);
-    if ((threadIdx.x & 63u) == 0 && n_surface) atomicAdd(&ctr->shaded[bounce], n_surface);
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = n_surface;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+        if (total) atomicAdd(&ctr->shaded_part[((uint32_t)bounce * 8u + (blockIdx.x & 7u)) * 32u], total);
+    }
 }
 
 // ------------------------------------------------------------------ the path kernel: every bounce of a wavefront in ONE launch
@@ -2036,7 +2044,10 @@ __global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (packet_primary) { tot->primary += QC(ctr, 0); tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
     unsigned long long c = 0, s = 0, sh = 0;
-    for (uint32_t b = 0; b < bounces; ++b) { c += QC(ctr, b); s += SC(ctr, b); sh += ctr->shaded[b]; }
+    for (uint32_t b = 0; b < bounces; ++b) {
+        c += QC(ctr, b); s += SC(ctr, b); sh += ctr->shaded[b];
+        for (uint32_t k = 0; k < 8u; ++k) sh += ctr->shaded_part[(b * 8u + k) * 32u];
+    }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
