@@ -358,32 +358,22 @@ def run(args):
         for uid in box[0]:
             comms.append(lp.Comm(dev, uid, rank, world))   # ncclCommInitRank inside the library (RCCL over xGMI)
     xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
-    # host-side gather: ONE frame in POSIX shared memory that every rank maps and page-locks, + a line of per-rank progress words for the frame barrier
+    # host-side gather: ONE frame in POSIX shared memory that every rank maps and page-locks, and its frame barrier — behind the C ABI
+    # (lpt_host_frame_*: shm + hipHostRegister + progress words with pause-spinning, then futex).  Every N>1 run gets one: the three exchange
+    # forms are timed in one run (exchange_forms below)
     shared = None
-    if host_gather:
-        box = [("/dev/shm/lpt_frame_%d_%d" % (os.getpid(), int(time.time() * 1e6))) if rank == 0 else None]
+    if world > 1 or (host_gather and use_dist):
+        box = [("/lpt_frame_%d_%d" % (os.getpid(), int(time.time() * 1e6))) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        shm_path = box[0]
-        n_f32 = HEIGHT * WIDTH * 4
         if rank == 0:
-            np.memmap(shm_path, dtype=np.float32, mode="w+", shape=(n_f32 + 64 * 16,)).flush()
+            shared = lp.HostFrame.create(box[0], WIDTH, HEIGHT, world)
         dist.barrier()
-        whole = np.memmap(shm_path, dtype=np.float32, mode="r+", shape=(n_f32 + 64 * 16,))
-        lp.host_register(whole)
-        shared = {"frame": whole[:n_f32].reshape(HEIGHT, WIDTH, 4), "words": whole[n_f32:].view(np.int32), "path": shm_path, "whole": whole, "no": 0}
+        if rank != 0:
+            shared = lp.HostFrame.attach(box[0], WIDTH, HEIGHT, world)
 
     def host_frame_barrier():
-        """every rank has written frame `no` (its word = no), rank 0 has seen all of them (word 16 * world = no): polling on shared memory, microseconds"""
-        shared["no"] += 1
-        no, wds = shared["no"], shared["words"]
-        wds[16 * rank] = no
-        if rank == 0:
-            while any(int(wds[16 * q]) < no for q in range(world)):
-                pass
-            wds[16 * world] = no
-        else:
-            while int(wds[16 * world]) < no:
-                pass
+        """every rank has written its pixels of this frame: lpt_host_frame_barrier (the frame number is the HostFrame's own counter)"""
+        shared.barrier(rank)
     desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"), texture_size=args.texture_size)
     tex_bytes = int(sum(im.size for im in desc["images"]))
     scene = scenes.to_product(desc)
@@ -395,15 +385,18 @@ def run(args):
     blit_mode = {"pathtrace": lp.BlitMode.Pahtrace, "temporal": lp.BlitMode.Temporal, "denoised": lp.BlitMode.DenoisedPathrace}[args.blit_mode]
     denoising = blit_mode != lp.BlitMode.Pahtrace
 
-    def exchange(rr):
+    def exchange(rr, form=None):
         if args.group_bracket:
             lp.Comm.group_begin()
-        rr.exchange(xmode)
+        rr.exchange(xmode if form is None else (lp.EXCHANGE_REDUCE if form == "reduce" else lp.EXCHANGE_GATHER_TILES))
         if args.group_bracket:
             lp.Comm.group_end()
 
-    def make_renderer(comm=None, lanes=None, shard=None):
+    def make_renderer(comm=None, lanes=None, shard=None, host_form=None, wts="default"):
+        """host_form: None = this run's main form (args.exchange); True / False = a renderer for the host-side gather / for an RCCL exchange"""
         shard = shard or args.emulate_shard
+        host_form = host_gather if host_form is None else host_form
+        wts = weights[0] if wts == "default" else wts
         rr = lp.Renderer(dev, (WIDTH, HEIGHT))
         if lanes:
             rr.set_lanes(lanes)
@@ -417,11 +410,11 @@ def run(args):
             rr.set_blit_mode(blit_mode)
         if args.sort:
             rr.set_sort_queues(args.sort)
-        if comm is not None:
-            rr.set_comm(comm, weights[0])          # = set_shard(rank, world, 32, 8, weights) + the binding
+        if comm is not None and not host_form:
+            rr.set_comm(comm, wts)                 # = set_shard(rank, world, 32, 8, weights) + the binding
             rr.set_resources(dev, sg, probe)
-        elif host_gather:
-            rr.set_shard(rank, world, 32, 8, weights=weights[0])
+        elif host_form:
+            rr.set_shard(rank, world, 32, 8, weights=wts)
             rr.set_resources(dev, sg, probe)
         elif shard > 1:
             rr.set_shard(0, shard, 32, 8)
@@ -442,24 +435,28 @@ def run(args):
     dst = None if args.pageable else lp.pinned_array((HEIGHT, WIDTH, 4))   # page-locked read-back destination (lpt_host_alloc)
     last = {}
 
-    def span_frame():
-        r.reset_accumulation()
-        r.accumulate = True                      # app.rs:318
+    def span_frame(rr=None, form=None):
+        """one frame in the SURVEY 8d span form on renderer rr (default: the timed one) ended by exchange form `form` (default: this run's)"""
+        rr = r if rr is None else rr
+        form = args.exchange if form is None else form
+        rccl_form = use_dist and form != "host"
+        rr.reset_accumulation()
+        rr.accumulate = True                     # app.rs:318
         for _ in range(SPP):
-            r.raytrace(view)                     # records; the four calls leave together at the next submission point
-            if comms and denoising:
-                exchange(r)                      # a denoising call is a frame of its own: its filter inputs travel, rank 0 filters
-        if comms and not denoising:
-            exchange(r)                          # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
-        if host_gather:
-            r.read_radiance_owned(shared["frame"])   # every rank: its own pixels into the one shared frame, over its own link
+            rr.raytrace(view)                    # records; the four calls leave together at the next submission point
+            if rccl_form and denoising:
+                exchange(rr, form)               # a denoising call is a frame of its own: its filter inputs travel, rank 0 filters
+        if rccl_form and not denoising:
+            exchange(rr, form)                   # RCCL on the renderer's stream, behind the frame's kernels; rank 0 presents the frame
+        if use_dist and form == "host" and shared is not None:
+            rr.read_radiance_owned(shared.array)     # every rank: its own pixels into the one shared frame, over its own link
             host_frame_barrier()                     # the frame is complete in host memory: the end of the §8d span
             if rank == 0:
-                last["img"] = shared["frame"]
+                last["img"] = shared.array
         elif rank == 0:
-            last["img"] = r.read_radiance(out=dst)   # blocking: the end of the §8d span
+            last["img"] = rr.read_radiance(out=dst)  # blocking: the end of the §8d span
         else:
-            r.synchronize()
+            rr.synchronize()
 
     for _ in range(args.warmup):
         for _ in range(FPS):
@@ -497,7 +494,7 @@ def run(args):
         # the weights of a communicator may sum to at most 64 (kMaxVirtual): beyond 8 ranks the others' weight shrinks with the world size
         # (and past 32 ranks — kMaxWorld for weighted shards — the shares stay equal)
         base = max(1, min(8, 64 // max(world, 1)))
-        w0 = max(0, min(base, int(round(w0 * base / 8.0))))
+        w0 = max(0 if denoising else 1, min(base, (w0 * base + 4) // 8))   # round half up (not Python's banker's rounding); Pathtrace keeps rank 0 tracing
         if w0 != base and world <= 32:
             weights[0] = [w0] + [base] * (world - 1)
             r.close()
@@ -536,6 +533,13 @@ def run(args):
     timings = r.timings()
     r.enable_timings(False)
     r.reset_ray_counts()
+    stage_ms_ranks = None
+    if use_dist:   # load imbalance of the interleaved tiles: every stage's per-frame time on the slowest and on the fastest rank
+        mine_ms = {k: v[0] / FPS for k, v in timings.items()}
+        allm = [None] * world
+        dist.all_gather_object(allm, mine_ms)
+        stage_ms_ranks = {k: {"max": max(m.get(k, 0.0) for m in allm), "min": min(m.get(k, 0.0) for m in allm), "rank_of_max": max(range(world), key=lambda q: allm[q].get(k, 0.0))}
+                          for k in sorted(set().union(*[set(m) for m in allm]))}
 
     tl = torch.tensor([elapsed], dtype=torch.float64)
     rays = torch.tensor([closest_l, shadow_l, shaded_l], dtype=torch.float64)
@@ -556,7 +560,7 @@ def run(args):
         img = last["img"]
         frame_ok = bool(np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img)) and float(img[..., :3].mean()) > 0.0)
         checksum = float(np.float64(img[..., :3].sum()))
-    if host_gather:
+    if host_gather and use_dist:
         # `img` IS the shared frame: no rank may start the next frame (the stats frame below writes its pixels into it) before rank 0 has read this one
         dist.barrier()
 
@@ -763,6 +767,58 @@ def run(args):
         for rr in rs:
             rr.close()
 
+    # ================================================================== N>1: the three exchange forms in ONE run ("implement ncclReduce first, then the compact
+    # variant, and report both"; the host-side gather is the third).  The timed region above used `--exchange`; the other two get 20 frames each here, on fresh
+    # renderers (RCCL forms: the calibrated tile weights if the main form calibrated them, else equal shares; host form: equal shares), same span, max over ranks.
+    exchange_forms = None
+    if use_dist and (world > 1 or args.force_dist) and not args.emulate_shard:
+        main_form = args.exchange
+        exchange_forms = {"what": "ms per frame and Mrays/s of the SAME frame ended by each exchange form, one process per GPU: gather = owned tiles by grouped ncclSend/ncclRecv "
+                                  "+ read_radiance on rank 0; reduce = ncclReduce(sum) of the whole radiance buffer + read_radiance on rank 0; host = every rank writes its own pixels "
+                                  "into one shared host frame (lpt_host_frame_*), no exchange on the GPUs.  `%s` is the timed region of this line, the others %d frames after 3 warm-up "
+                                  "frames; frame_checksum = sum of the RGB of the frame rank 0 ends up with — the three must be equal" % (main_form, 20),
+                          main_form: {"ms_per_frame": elapsed / n_frames * 1e3, "Mrays_s": (closest + shadow) / elapsed / 1e6, "frame_checksum": checksum, "frames": n_frames, "timed_region": True}}
+        lazy_comms = []
+        for form in ("gather", "reduce", "host"):
+            if form == main_form:
+                continue
+            try:
+                if form == "host":
+                    if shared is None:
+                        raise RuntimeError("no shared host frame (one rank)")
+                    rr = make_renderer(None, lanes=args.lanes or None, host_form=True, wts=None)
+                else:
+                    if not comms and not lazy_comms:   # the main form was `host`: RCCL comes up only now (and a failure here cannot take the headline down)
+                        box = [lp.Comm.unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(box, src=0)
+                        lazy_comms.append(lp.Comm(dev, box[0], rank, world))
+                    rr = make_renderer((comms or lazy_comms)[0], lanes=args.lanes or None, host_form=False)
+                for _ in range(3):
+                    span_frame(rr, form)
+                rr.reset_ray_counts()
+                fence([rr])
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    span_frame(rr, form)
+                fence([rr])
+                dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+                cc = rr.ray_counts()
+                ry = torch.tensor([float(cc.closest + cc.shadow)], dtype=torch.float64)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+                ck = float(np.float64(last["img"][..., :3].sum())) if rank == 0 else None
+                dist.barrier()          # the host form's image IS the shared frame: read before anybody renders into it again
+                exchange_forms[form] = {"ms_per_frame": float(dt.item()) / 20 * 1e3, "Mrays_s": float(ry.item()) / float(dt.item()) / 1e6, "frame_checksum": ck, "frames": 20, "timed_region": False}
+                rr.close()
+            except Exception as e:   # noqa: BLE001 - an extra leg must not cost the line
+                exchange_forms[form] = {"error": "%s: %s" % (type(e).__name__, e)}
+        comms = comms + lazy_comms
+        if rank == 0:
+            cks = [v.get("frame_checksum") for k, v in exchange_forms.items() if isinstance(v, dict) and "frame_checksum" in v]
+            exchange_forms["checksums_equal"] = bool(len(cks) >= 2 and all(c == cks[0] for c in cks))
+            if not exchange_forms["checksums_equal"]:
+                print("bench.py: the exchange forms do not end in the same frame: %r" % ({k: v for k, v in exchange_forms.items() if k != "what"},), file=sys.stderr)
+
     host_gather_j = None
     if host_gather:
         host_gather_j = {"what": "no exchange on the GPUs: every rank wrote its owned pixels of the mean radiance into ONE shared-memory frame (lpt_renderer_read_radiance_owned), "
@@ -818,6 +874,8 @@ def run(args):
             "shard_emulation": shard_emulation,
             "rccl": rccl,
             "host_gather": host_gather_j,
+            "exchange_forms": exchange_forms,
+            "stage_ms_per_rank": stage_ms_ranks,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": rf_frac,
                          # the same launches against the bytes that actually crossed the fabric (replayed counter figure / this run's launch time): the
@@ -856,13 +914,8 @@ def run(args):
     if use_dist:
         dist.barrier()
     if shared is not None:
-        shared["frame"] = shared["words"] = None
-        lp.host_unregister(shared["whole"])
-        if rank == 0:
-            try:
-                os.unlink(shared["path"])
-            except OSError:
-                pass
+        last.pop("img", None)
+        shared.close()       # unregister + unmap; the creator (rank 0) unlinks
     for c in comms:
         c.close()
     if use_dist:

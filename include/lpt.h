@@ -415,6 +415,24 @@ int lpt_host_unregister(void *ptr);
  * and a host-side barrier completes the frame: the alternative to lpt_renderer_exchange + lpt_renderer_read_radiance on rank 0
  * (DESIGN 6).  BlitMode::Pathtrace only.  Blocking. */
 int lpt_renderer_read_radiance_owned(lpt_renderer *r, float *frame_dst);
+/* new (multi-GPU, HOST-SIDE GATHER behind the boundary; replaces, on N ranks, the one blocking call the reference ends a frame with:
+ * async Renderer::read_pixels, renderer.rs:727-811 — copy to a staging buffer, map it, device.poll(Wait)).  ONE whole frame (w*h*4 floats)
+ * in POSIX shared memory that every rank of a node maps and page-locks; every rank writes its OWN pixels into it straight from its GPU
+ * (lpt_renderer_read_radiance_owned(r, frame)) and lpt_host_frame_barrier completes the frame: a line of per-rank progress words in the same
+ * segment, pause-spinning for the first microseconds, then futex sleeps.  Rank 0 creates (`name` as for shm_open: "/something"; fails with
+ * LPT_ERR_FILE_NOT_FOUND if it exists), the other ranks attach once rank 0 has (the name travels out of band, like the communicator id);
+ * destroy unmaps, the creator also unlinks.  A device must exist first (the segment is registered with HIP) unless LPT_HOST_FRAME_HOST_ONLY is
+ * passed: a participant that only reads the finished frame (a compositor or encoder process) needs no GPU.  `world` = the barrier's participants. */
+typedef struct lpt_host_frame lpt_host_frame;
+enum { LPT_HOST_FRAME_HOST_ONLY = 1 };
+int lpt_host_frame_create(const char *name, uint32_t width, uint32_t height, uint32_t world, uint32_t flags, lpt_host_frame **out);
+int lpt_host_frame_attach(const char *name, uint32_t width, uint32_t height, uint32_t world, uint32_t flags, lpt_host_frame **out);
+/* the frame: width * height * 4 floats, row-major, in page-locked shared memory (valid until lpt_host_frame_destroy) */
+int lpt_host_frame_ptr(lpt_host_frame *f, float **frame);
+/* returns when every one of the `world` participants has called it with this frame number (1, 2, 3, ...: the caller's frame counter, the same
+ * on every rank; a rank calls it after its lpt_renderer_read_radiance_owned of that frame has returned).  LPT_ERR_READBACK after timeout_ms. */
+int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, uint32_t timeout_ms);
+int lpt_host_frame_destroy(lpt_host_frame *f);
 /* replaces: renderer.queries.values()/labels()
  * (crates/standalone/src/gui/windows/performance_info.rs:19-20) */
 int lpt_renderer_get_timings(lpt_renderer *r, lpt_timing *out, int *inout_count);
@@ -555,8 +573,8 @@ typedef enum lpt_option {
                                      * flight shades 64 hits of one kind with all its lanes; no chip-wide barrier per bounce (renderer.rs:484-509) and no
                                      * lane that waits for its own wave's shading batch.  0: never */
     LPT_OPT_POOL_SHADERS = 16,      /* pool kernel: waves of a block that prefer shading to tracing (default 2) */
-    LPT_OPT_POOL_ENTRIES = 17,      /* pool kernel: path records per block, a power of two in 256..32768 (default 4096) */
-    LPT_OPT_POOL_WAVES = 18,        /* pool kernel: waves per block, 4 / 8 / 16 (default 16: one block per CU) */
+    LPT_OPT_POOL_ENTRIES = 17,      /* pool kernel: path records per block, 0 (default: 256 per wave of a block) or a power of two in 256..32768 */
+    LPT_OPT_POOL_WAVES = 18,        /* pool kernel: waves per block, 4 / 8 / 16 (default 8: two blocks per CU) */
     LPT_OPT_POOL_REFILL = 19,       /* pool kernel: lanes tracing at or below which a wave retires its finished rays and refills (default 44) */
     LPT_OPT_SPLIT_RAYS = 20,        /* a batch above this many rays that would still fit one wavefront leaves as two, on the renderer's lanes (default
                                      * 3 000 000; 0: never split below LPT_OPT_WAVEFRONT_RAYS) */

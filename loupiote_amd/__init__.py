@@ -10,5 +10,5 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from ._abi import EXCHANGE_GATHER_TILES, EXCHANGE_REDUCE, INVALID_INDEX, LIB_PATH, LIGHT_BIT  # noqa: F401
 from .api import (BlitMode, CameraController, Comm, Device, Error, ProbeGPU, Renderer, Scene, SceneGPU,  # noqa: F401
-                  decode_image, default_light, host_register, host_unregister, load_blue_noise, load_env, load_env_path, loaders, pinned_array, save_radiance,
+                  decode_image, default_light, HostFrame, host_register, host_unregister, load_blue_noise, load_env, load_env_path, loaders, pinned_array, save_radiance,
                   save_screenshot)

@@ -24,6 +24,7 @@ OPTIONS = {"merge_trace": 1, "packet_primary": 2, "pipe_rays": 3, "wavefront_ray
            "shade_blocks_per_cu": 7, "path_rays": 8, "path_waves_per_cu": 9, "path_refill": 10, "occ_cell_milli": 11, "step_budget": 12, "budget_rays": 13, "packet_quads": 14,
            "pool_rays": 15, "pool_shaders": 16, "pool_entries": 17, "pool_waves": 18, "pool_refill": 19, "split_rays": 20, "budget_split": 21}
 EXCHANGE_GATHER_TILES = 0
+HOST_FRAME_HOST_ONLY = 1
 EXCHANGE_REDUCE = 1
 INVALID_INDEX = 0xFFFFFFFF
 LIGHT_BIT = 0x80000000
@@ -125,6 +126,11 @@ SIGNATURES = {
     "lpt_host_register": (_i, [_vp, _sz]),
     "lpt_host_unregister": (_i, [_vp]),
     "lpt_renderer_read_radiance_owned": (_i, [_vp, _vp]),
+    "lpt_host_frame_create": (_i, [C.c_char_p, _u32, _u32, _u32, _u32, _pvp]),
+    "lpt_host_frame_attach": (_i, [C.c_char_p, _u32, _u32, _u32, _u32, _pvp]),
+    "lpt_host_frame_ptr": (_i, [_vp, _pvp]),
+    "lpt_host_frame_barrier": (_i, [_vp, _u32, _u32, _u32]),
+    "lpt_host_frame_destroy": (_i, [_vp]),
     "lpt_renderer_reset_accumulation": (_i, [_vp]),
     "lpt_renderer_set_accumulate": (_i, [_vp, _i]),
     "lpt_renderer_get_accumulate": (_i, [_vp, C.POINTER(_i)]),

@@ -569,6 +569,46 @@ class _PinnedBlock:
             pass
 
 
+class HostFrame:
+    """The host-side gather of a tile-sharded frame (lpt_host_frame_*): ONE whole frame in POSIX shared memory that every rank of a node maps and
+    page-locks.  Rank 0: `HostFrame.create(name, w, h, world)`; the others, once rank 0 has: `HostFrame.attach(...)`.  Per frame every rank calls
+    `renderer.read_radiance_owned(frame.array)` (its own pixels, over its own PCIe link) and then `frame.barrier(rank, frame_no)`; after the
+    barrier `frame.array` (h, w, 4 float32) is the complete frame on every rank.  `host_only`: a participant without a GPU (it only reads)."""
+
+    def __init__(self, handle, width, height, world):
+        self._h, self.width, self.height, self.world = handle, width, height, world
+        p = C.c_void_p()
+        _check(A.lib().lpt_host_frame_ptr(self._h, C.byref(p)))
+        buf = (C.c_float * (width * height * 4)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=np.float32).reshape(height, width, 4)
+        self.frame_no = 0
+
+    @classmethod
+    def create(cls, name, width, height, world, host_only=False):
+        h = C.c_void_p()
+        _check(A.lib().lpt_host_frame_create(name.encode(), width, height, world, A.HOST_FRAME_HOST_ONLY if host_only else 0, C.byref(h)))
+        return cls(h, width, height, world)
+
+    @classmethod
+    def attach(cls, name, width, height, world, host_only=False):
+        h = C.c_void_p()
+        _check(A.lib().lpt_host_frame_attach(name.encode(), width, height, world, A.HOST_FRAME_HOST_ONLY if host_only else 0, C.byref(h)))
+        return cls(h, width, height, world)
+
+    def barrier(self, rank, frame_no=None, timeout_ms=60000):
+        """frame_no None: this object's own counter (every rank calls barrier once per frame)"""
+        if frame_no is None:
+            self.frame_no += 1
+            frame_no = self.frame_no
+        _check(A.lib().lpt_host_frame_barrier(self._h, rank, frame_no, timeout_ms))
+
+    def close(self):
+        if self._h:
+            self.array = None
+            A.lib().lpt_host_frame_destroy(self._h)
+            self._h = None
+
+
 def host_register(array):
     """page-lock and map an existing C-contiguous numpy array (e.g. over a shared-memory segment) for the device: lpt_host_register"""
     _check(A.lib().lpt_host_register(A.ptr(array), array.nbytes))

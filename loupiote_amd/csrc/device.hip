@@ -243,7 +243,7 @@ struct lpt_renderer {
     bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
     uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
     // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
-    uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 4096u, pool_waves = 16u;
+    uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 0u, pool_waves = 8u;   // pool_entries 0: 256 records per wave of a block
     int pool_refill = 44;
     uint32_t *err_host = nullptr, *err_dev = nullptr;   // the device's error word: one page-locked host word the kernels write (a bounded wait that ran out), checked behind every blocking call
     bool packet_quads = true;      // a packet of bounce 0 = the four samples of a 4x4-pixel quarter (where the queue order allows it) instead of one sample of an 8x8 patch (LPT_OPT_PACKET_QUADS)
@@ -554,6 +554,10 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     hipSetDevice(sg->dev->ordinal);
     flush_device(sg->dev);
     hipDeviceSynchronize();   // renderers trace on their own streams: frames still in flight read what is freed here
+    // a renderer still bound to this scene is detached (a host that drops the scene first must not leave the renderer with a dangling
+    // pointer): its next raytrace() is the no-op of a renderer without resources (renderer.rs:403-407) until set_resources is called again
+    for (lpt_renderer *r : sg->dev->renderers)
+        if (r->sg == sg) { r->sg = nullptr; r->resources_set = false; }
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
                     sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena, sg->pair_texels, sg->pair_images};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -933,6 +937,8 @@ int lpt_probe_destroy(lpt_probe *p) {
     hipSetDevice(p->dev->ordinal);
     flush_device(p->dev);
     hipDeviceSynchronize();   // frames in flight on the renderers' streams may still sample the probe
+    for (lpt_renderer *r : p->dev->renderers)   // a renderer still bound to it falls back to the 1x1 default probe (renderer.rs:693-696)
+        if (r->probe == p) r->probe = nullptr;
     if (p->rgbe) hipFree(p->rgbe);
     delete p;
     return LPT_OK;
@@ -1446,7 +1452,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_PACKET_QUADS: r->packet_quads = value != 0; break;
     case LPT_OPT_POOL_RAYS: r->pool_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_POOL_SHADERS: if (value > 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_SHADERS: 0..16"); r->pool_shaders = (uint32_t)value; break;
-    case LPT_OPT_POOL_ENTRIES: if (value < 256u || value > 32768u || (value & (value - 1u))) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_ENTRIES: a power of two in 256..32768"); r->pool_entries = (uint32_t)value; break;
+    case LPT_OPT_POOL_ENTRIES: if (value && (value < 256u || value > 32768u || (value & (value - 1u)))) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_ENTRIES: 0 (256 per wave of a block) or a power of two in 256..32768"); r->pool_entries = (uint32_t)value; break;
     case LPT_OPT_POOL_WAVES: if (value != 4u && value != 8u && value != 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_WAVES: 4, 8 or 16"); r->pool_waves = (uint32_t)value; break;
     case LPT_OPT_POOL_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_REFILL: 0..63"); r->pool_refill = (int)value; break;
     case LPT_OPT_SPLIT_RAYS: r->split_rays = value; break;
@@ -1717,7 +1723,9 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
         // the step budget pays where nothing else fills the tail of a launch: a submission that is ONE wavefront (a tile shard, a small frame).  The
         // pieces of a cut batch overlap on the renderer's lanes and hide each other's tails: 1/2 shard as two wavefronts 6.84 ms without, 6.93 with it
-        const uint32_t budget = (r->step_budget && (solo || r->budget_split) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
+        // (not with the stats kernels: a ray dropped at the budget would be missing from the steps-per-ray histogram and its partial node / triangle counts would be
+        // counted again by the cooperative kernel's full re-trace — ADVICE r04)
+        const uint32_t budget = (!r->stats && r->step_budget && (solo || r->budget_split) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
@@ -1736,8 +1744,9 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         };
         // The pool kernel (pool_kernels.h) for wavefronts above the path kernel's range: one block of pool_waves waves per 16 wave slots of a CU, its LDS
         // (traversal stacks of every wave + the rings) must fit the CU's 160 KB — a tree too deep for that takes the per-bounce launches
-        const uint32_t pool_lds = pool_lds_bytes(sc.stack_entries, r->pool_waves, r->pool_entries);
-        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && pool_lds <= 160u * 1024u;
+        const uint32_t pool_entries = r->pool_entries ? r->pool_entries : 256u * r->pool_waves, pool_trace_cap = 64u * r->pool_waves;
+        const uint32_t pool_lds = pool_lds_bytes(sc.stack_entries, r->pool_waves, pool_entries, pool_trace_cap);
+        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && pool_lds * (16u / r->pool_waves) <= 160u * 1024u;
         if (r->merge_trace) {
             if (packet) {
                 // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
@@ -1769,7 +1778,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         if (use_pool) {
             stage_begin(r, ST_PATH, s);
             const uint32_t blocks = cus * (16u / r->pool_waves);
-            const size_t need = (size_t)blocks * r->pool_entries * kPoolRec;
+            const size_t need = (size_t)blocks * pool_entries * kPoolRec;
             if (wf.pool_slab_elems < need) {
                 HIP_TRY(hipStreamSynchronize(s));
                 if (wf.pool_slab) HIP_TRY(hipFree(wf.pool_slab));
@@ -1777,7 +1786,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 HIP_TRY(hipMalloc(&wf.pool_slab, sizeof(float4) * need));
                 wf.pool_slab_elems = need;
             }
-            PoolArgs pa{wf.pool_slab, r->pool_entries, std::min(r->pool_shaders, r->pool_waves), r->pool_refill, 256u, r->err_dev};
+            PoolArgs pa{wf.pool_slab, pool_entries, pool_trace_cap, std::min(r->pool_shaders, r->pool_waves), r->pool_refill, 256u, r->err_dev};
             const float4 *h0 = packet ? wf.hits : (const float4 *)nullptr;
             static bool attr_set = false;
             if (!attr_set) {   // more than 64 KB of dynamic LDS needs the attribute
@@ -2295,6 +2304,11 @@ int lpt_comm_create(lpt_device *dev, const void *id_bytes, int rank, int world, 
 int lpt_comm_destroy(lpt_comm *c) {
     if (!c) return LPT_OK;
     hipSetDevice(c->dev->ordinal);
+    // renderers still bound to the communicator: their recorded frames leave first, then they are unbound (they keep their shard of the frame; an
+    // exchange on them is then the single-GPU no-op instead of a call into a destroyed communicator)
+    flush_device(c->dev);
+    for (lpt_renderer *r : c->dev->renderers)
+        if (r->comm == c) { forget_deferred_exchange(r); hipStreamSynchronize(r->stream); r->comm = nullptr; }
     if (c->comm && rccl()) rccl()->CommDestroy(c->comm);
     delete c;
     return LPT_OK;

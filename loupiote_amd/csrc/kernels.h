@@ -411,7 +411,12 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
         const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
         if (STATS) n_nodes++;
         const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;
+#ifdef LPT_EXP_NOMUL
+        const uint32_t oinv2 = rs.oinv | (rs.oinv << 8);
+        const uint32_t oinv4 = oinv2 | (oinv2 << 16);   // = oinv * 0x01010101 without the quarter-rate v_mul_lo_u32
+#else
         const uint32_t oinv4 = rs.oinv * 0x01010101u;
+#endif
         // t(q) = q * a + b per axis; a is exact (power-of-two step times 1/d), b carries three roundings.
         // |error of the computed t| <= 2^-24 * (4|b| + 510|a|), so widening b by eps = 2^-21 * (|b| + 255|a|)
         // towards the outside on both ends keeps the test conservative wherever the ray starts.
@@ -433,7 +438,12 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
         for (int half = 0; half < 2; ++half) {
             const uint32_t meta4 = half ? n1.w : n1.z;
             const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+#ifdef LPT_EXP_NOMUL
+            const uint32_t inner1 = is_inner4 >> 4;
+            const uint32_t inner_mask4 = (inner1 << 8) - inner1;   // = inner1 * 0xFF modulo 2^32
+#else
             const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
+#endif
             const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
             const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
             const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
@@ -453,6 +463,16 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
                 if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
+#ifdef LPT_EXP_DUPMASK
+                // ceiling probe (A/B builds only, `make variant`): the hit-mask assembly of the first LPT_EXP_DUPMASK children a SECOND time on
+                // operands the compiler cannot see through — the same value OR-ed in again, so the frame does not change; what the launch loses is what these
+                // instructions cost where they stand
+                if (4 * half + j < LPT_EXP_DUPMASK) {
+                    uint32_t cb = child_bits4;
+                    asm volatile("" : "+v"(cb));
+                    if (tn <= tf) hitmask |= ((cb >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
+                }
+#endif
             }
         }
         rs.ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));

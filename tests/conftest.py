@@ -40,16 +40,25 @@ def device():
     dev.close()
 
 
-@pytest.fixture(params=["path", "per_bounce"])
+PIPELINES = {
+    # every bounce behind the primary hits in ONE launch, a lane carries a path (k_path), whatever the size of the wavefront; bounce 0 through the packet
+    # kernel at every resolution (the default picks it by pixel footprint: not for the small frames most tests render)
+    "path": {"path_rays": 0x7FFFFFFF, "packet_primary": 1},
+    # the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace) with a step budget of 16 (default 48), so that in every parity test a good part of the
+    # rays is finished by the wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; the packet choice is the library's
+    "per_bounce": {"path_rays": 0, "step_budget": 16},
+    # round 5: the CU-local pool of trace and shade work (k_pool): records handed between the waves of a block through LDS rings, hits shaded by kind
+    "pool": {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "packet_primary": 1},
+    # the configuration as shipped: nothing forced (kernel choice by ray count and pixel footprint, default budget, quad packets) — ADVICE r04
+    "default": {},
+}
+
+
+@pytest.fixture(params=list(PIPELINES))
 def pipeline(request, monkeypatch):
-    """Runs a test body over both forms of the frame pipeline: every bounce behind the primary hits in ONE launch (k_path, whatever the
-    size of the wavefront) and the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace).  The library picks between them by
-    the wavefront's ray count (LPT_OPT_PATH_RAYS); both must give the oracle's frame at every size.  Modules opt in with
+    """Runs a test body over every form of the frame pipeline (PIPELINES above) and over the shipped defaults.  The library picks between the forms by
+    the wavefront's ray count (LPT_OPT_PATH_RAYS, LPT_OPT_POOL_RAYS); all of them must give the oracle's frame at every size.  Modules opt in with
     `pytestmark = pytest.mark.usefixtures("pipeline")`."""
     from loupiote_amd import api
-    # the "path" arm also forces bounce 0 through the packet kernel at every resolution (the default picks it by pixel footprint: not for the
-    # small frames most tests render), the "per_bounce" arm leaves that choice to the library
-    # ... and runs its traversal launches with a step budget of 16 (default 48), so that in every parity test a good part of the rays is finished by the
-    # wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; wavefronts too large for the budget (the full-size vectors) run without
-    monkeypatch.setattr(api, "DEFAULT_OPTIONS", {"path_rays": 0x7FFFFFFF, "packet_primary": 1} if request.param == "path" else {"path_rays": 0, "step_budget": 16})
+    monkeypatch.setattr(api, "DEFAULT_OPTIONS", dict(PIPELINES[request.param]))
     return request.param
