@@ -272,6 +272,28 @@ def load_profile_json(name):
     return None
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the device code: what profiles/limits.json and traffic.json record of the tree they were measured on (tools/limits_from_pmc.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.h", "pool_kernels.h", "device_math.h"):
+        try:
+            h.update(open(os.path.join(ROOT, "loupiote_amd", "csrc", f), "rb").read())
+        except OSError:
+            pass
+    return h.hexdigest()[:16]
+
+
+def fixed_traversal_counts():
+    """SURVEY 8d: the per-unit figure of the roofline is FIXED per config — mean nodes visited / triangles tested per ray of config 4, committed with the
+    fixtures (tests/golden/cfg4_traversal_counts.json: the counts of the kernel variant that fetches least, the two-round-trip step) — so that `roofline.frac`
+    compares across builds: a build that fetches more per ray does not score higher (VERDICT r04 #6).  None when the file is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4_traversal_counts.json")))
+    except Exception:
+        return None
+
+
 def from_profiles_object(avg_launch_ms):
     """What the bench line REPLAYS from committed profile summaries (profiles/traffic.json, profiles/limits.json: rocprofv3 --pmc passes of an
     earlier run of the same command, tools/profile.sh) — kept under ONE key so that a reader of the line cannot take it for something
@@ -287,8 +309,12 @@ def from_profiles_object(avg_launch_ms):
                            "the bytes a ray pulls through the CU's vector-memory path (measured: fewer or cheaper VALU instructions change nothing, more bytes or "
                            "fewer cached nodes do — DESIGN 5.1), quoted here against the 9.7-13.5 TB/s a fully divergent dwordx4 gather reaches in the "
                            "microbenchmark; the VALU issue rate against its own microbenchmark ceiling rides along"}
+    here = kernel_source_hash()
+    measured_on = (limits_j or {}).get("kernel_source_hash") or traffic_j.get("kernel_source_hash")
     obj = {"what": "replayed from committed rocprofv3 --pmc summaries of an earlier run of this command — NOT measured in this run",
            "source": {"traffic": traffic_j.get("source"), "limits": (limits_j or {}).get("source")},
+           # the device code the counters were measured on against the device code of this tree: a changed kernel with un-refreshed profiles says so
+           "kernel_source_hash": {"profiles": measured_on, "this_tree": here}, "stale": measured_on != here,
            "traffic": traffic, "traffic_unit": "fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE) per k_trace launch",
            "limits": limits_j, "binding_limit": binding}
     return obj, traffic
@@ -616,6 +642,16 @@ def run(args):
     r.set_max_fused(args.max_fused)
     s_avg, s_launches, s_bytes, s_achieved = trace_stage(solo_t, sc_.closest - sc_.primary, sc_.shadow)
     rays_per_launch = (sc_.closest - sc_.primary + sc_.shadow) / max(s_launches, 1)
+    # the roofline's per-ray bytes are a FIXED figure per config (committed counts), so that `frac` compares across builds; what THIS build's kernel
+    # really fetched (its own stats variant, above) is `frac_fetched` — a build that fetches more per ray scores higher there, not in `frac`
+    fixed = fixed_traversal_counts()
+    if fixed and WIDTH == 1920 and HEIGHT == 1080 and SPP == 4:
+        fb_ray = 32.0 + 16.0 + fixed["nodes_per_ray"] * accel.node_bytes + fixed["tris_per_ray"] * accel.tri_bytes
+        fb_sh = 32.0 + 4.0 + fixed["shadow_nodes_per_ray"] * accel.node_bytes + fixed["shadow_tris_per_ray"] * accel.tri_bytes
+        fixed_bytes = ((sc_.closest - sc_.primary) * fb_ray + sc_.shadow * fb_sh) / max(s_launches, 1)
+        fixed_achieved = fixed_bytes / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
+    else:   # another workload than config 4 (experiments), or no committed counts: the fetched figure is all there is
+        fixed, fb_ray, fb_sh, fixed_bytes, fixed_achieved = None, b_ray, b_sh, s_bytes, s_achieved
     pk_ms, pk_launches = solo_t.get("primary intersection", (0.0, 0))
     packet_j = None
     if pk_launches:
@@ -623,6 +659,7 @@ def run(args):
         pk_bytes = 32.0 * 64 + 16.0 * 64 + pk_nodes * accel.node_bytes + pk_tris * accel.tri_bytes      # per packet: 64 rays read, 64 hits written, the nodes / triangles once
         packet_j = {"kernel": "k_trace_packet", "what": "bounce 0: one tree walk per 64 coherent primary rays (the four samples of a 4x4-pixel patch), node and triangle fetches by scalar loads",
                     "avg_launch_ms": pk_avg, "launches": pk_launches, "rays_per_launch": sc_.primary / pk_launches, "Mrays_per_s": sc_.primary / pk_launches / (pk_avg * 1e-3) / 1e6,
+                    "Grays_per_s": sc_.primary / pk_launches / (pk_avg * 1e-3) / 1e9,
                     "nodes_per_packet": pk_nodes, "tris_per_packet": pk_tris, "bytes_per_packet": pk_bytes,
                     "achieved_GBps": sc_.primary / 64.0 / pk_launches * pk_bytes / (pk_avg * 1e-3) / 1e9}
     exchange_ms = timings.get("exchange", (0.0, 0))
@@ -771,17 +808,16 @@ def run(args):
     # variant, and report both"; the host-side gather is the third).  The timed region above used `--exchange`; the other two get 20 frames each here, on fresh
     # renderers (RCCL forms: the calibrated tile weights if the main form calibrated them, else equal shares; host form: equal shares), same span, max over ranks.
     exchange_forms = None
-    if use_dist and (world > 1 or args.force_dist) and not args.emulate_shard:
+    lazy_comms = []
+    if use_dist and (world > 1 or args.force_dist) and not args.emulate_shard and not denoising:
         main_form = args.exchange
         exchange_forms = {"what": "ms per frame and Mrays/s of the SAME frame ended by each exchange form, one process per GPU: gather = owned tiles by grouped ncclSend/ncclRecv "
                                   "+ read_radiance on rank 0; reduce = ncclReduce(sum) of the whole radiance buffer + read_radiance on rank 0; host = every rank writes its own pixels "
-                                  "into one shared host frame (lpt_host_frame_*), no exchange on the GPUs.  `%s` is the timed region of this line, the others %d frames after 3 warm-up "
-                                  "frames; frame_checksum = sum of the RGB of the frame rank 0 ends up with — the three must be equal" % (main_form, 20),
-                          main_form: {"ms_per_frame": elapsed / n_frames * 1e3, "Mrays_s": (closest + shadow) / elapsed / 1e6, "frame_checksum": checksum, "frames": n_frames, "timed_region": True}}
-        lazy_comms = []
+                                  "into one shared host frame (lpt_host_frame_*), no exchange on the GPUs.  `%s` is the timed region of this line, the others 20 frames after 3 warm-up "
+                                  "frames.  frame_checksum = sum of the RGB of the FIRST frame of a fresh renderer ended by that form, on rank 0 (a renderer's seed counter never "
+                                  "rewinds, so only frames of equal index compare) — the three must be equal" % main_form,
+                          main_form: {"ms_per_frame": elapsed / n_frames * 1e3, "Mrays_s": (closest + shadow) / elapsed / 1e6, "frames": n_frames, "timed_region": True}}
         for form in ("gather", "reduce", "host"):
-            if form == main_form:
-                continue
             try:
                 if form == "host":
                     if shared is None:
@@ -793,26 +829,32 @@ def run(args):
                         dist.broadcast_object_list(box, src=0)
                         lazy_comms.append(lp.Comm(dev, box[0], rank, world))
                     rr = make_renderer((comms or lazy_comms)[0], lanes=args.lanes or None, host_form=False)
-                for _ in range(3):
-                    span_frame(rr, form)
-                rr.reset_ray_counts()
-                fence([rr])
-                t1 = time.perf_counter()
-                for _ in range(20):
-                    span_frame(rr, form)
-                fence([rr])
-                dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-                cc = rr.ray_counts()
-                ry = torch.tensor([float(cc.closest + cc.shadow)], dtype=torch.float64)
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+                span_frame(rr, form)    # the first frame of a fresh renderer: the one whose checksum compares across the forms
                 ck = float(np.float64(last["img"][..., :3].sum())) if rank == 0 else None
                 dist.barrier()          # the host form's image IS the shared frame: read before anybody renders into it again
-                exchange_forms[form] = {"ms_per_frame": float(dt.item()) / 20 * 1e3, "Mrays_s": float(ry.item()) / float(dt.item()) / 1e6, "frame_checksum": ck, "frames": 20, "timed_region": False}
+                if form == main_form:
+                    exchange_forms[form]["frame_checksum"] = ck      # its times are the timed region's
+                else:
+                    for _ in range(2):
+                        span_frame(rr, form)
+                    rr.reset_ray_counts()
+                    fence([rr])
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        span_frame(rr, form)
+                    fence([rr])
+                    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+                    cc = rr.ray_counts()
+                    ry = torch.tensor([float(cc.closest + cc.shadow)], dtype=torch.float64)
+                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+                    exchange_forms[form] = {"ms_per_frame": float(dt.item()) / 20 * 1e3, "Mrays_s": float(ry.item()) / float(dt.item()) / 1e6, "frame_checksum": ck, "frames": 20, "timed_region": False}
                 rr.close()
             except Exception as e:   # noqa: BLE001 - an extra leg must not cost the line
-                exchange_forms[form] = {"error": "%s: %s" % (type(e).__name__, e)}
-        comms = comms + lazy_comms
+                if form == main_form:
+                    exchange_forms[form]["error"] = "%s: %s" % (type(e).__name__, e)
+                else:
+                    exchange_forms[form] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             cks = [v.get("frame_checksum") for k, v in exchange_forms.items() if isinstance(v, dict) and "frame_checksum" in v]
             exchange_forms["checksums_equal"] = bool(len(cks) >= 2 and all(c == cks[0] for c in cks))
@@ -838,7 +880,8 @@ def run(args):
     out = None
     if rank == 0:
         profiles_j, fabric_bytes = from_profiles_object(s_avg)
-        rf_frac, rf_frac_fabric = roofline_fractions(s_achieved, fabric_bytes, s_avg)
+        rf_frac, rf_frac_fabric = roofline_fractions(fixed_achieved, fabric_bytes, s_avg)
+        rf_frac_fetched = s_achieved / HBM_PEAK_GBS
         out = {
             "metric": baseline_metric(),
             "value": (closest + shadow) / elapsed / 1e6,
@@ -876,13 +919,19 @@ def run(args):
             "host_gather": host_gather_j,
             "exchange_forms": exchange_forms,
             "stage_ms_per_rank": stage_ms_ranks,
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": s_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": fixed_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": rf_frac,
+                         # `frac` / `achieved`: the FIXED algorithmic bytes per ray of config 4 (tests/golden/cfg4_traversal_counts.json) x the rays a launch carries —
+                         # comparable across builds.  `frac_fetched`: the bytes THIS build's kernel fetched per ray (its own stats variant): last round's `frac`.
+                         "frac_fetched": rf_frac_fetched, "achieved_fetched": s_achieved, "bytes_per_launch_fetched": s_bytes,
+                         "fixed_counts": fixed, "bytes_per_ray_fixed": fb_ray, "bytes_per_shadow_ray_fixed": fb_sh,
+                         # the comparable speed figure: rays per second of the un-overlapped launch
+                         "Grays_per_s": rays_per_launch / (s_avg * 1e-3) / 1e9 if s_avg > 0 else None,
                          # the same launches against the bytes that actually crossed the fabric (replayed counter figure / this run's launch time): the
                          # HBM-side utilisation.  `frac` says the caches serve the algorithmic bytes as fast as HBM could; this says how busy HBM is.
                          "frac_fabric": rf_frac_fabric,
                          "traffic": fabric_bytes, "traffic_is": "from_profiles (replayed, see roofline.from_profiles.source), not measured in this run",
-                         "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": s_bytes,
+                         "avg_launch_ms": s_avg, "launches": s_launches, "bytes_per_launch": fixed_bytes,
                          "basis": "un-overlapped launches: %d frames issued as one 4-sample wavefront each (lpt_renderer_set_max_fused(4)), one frame at a time, HIP events on the "
                                   "stream the kernel runs on around every k_trace launch — the duration rocprofv3's kernel trace reports for `bench.py --max-fused 4 --lanes 1` "
                                   "(profiles/*_solo_kernel_stats.csv)" % SOLO_FRAMES,
@@ -916,7 +965,7 @@ def run(args):
     if shared is not None:
         last.pop("img", None)
         shared.close()       # unregister + unmap; the creator (rank 0) unlinks
-    for c in comms:
+    for c in comms + lazy_comms:
         c.close()
     if use_dist:
         dist.destroy_process_group()

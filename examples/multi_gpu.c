@@ -7,8 +7,10 @@
  *       RCCL id to LPT_ID_FILE, the others read it; lpt_comm_create (ncclCommInitRank); lpt_renderer_exchange per frame.
  *   otherwise                               -> all N ranks inside this process on device 0 (N sharded renderers,
  *       lpt_renderer_exchange_local): the single-process form, and how the example runs on a one-GPU box.
- * Rank 0 prints a checksum of the presented frame; it does not depend on N (the N-GPU image is the 1-GPU image bit for bit) — and, in the
- * single-process form, the checksum of the same frame assembled by the host-side gather (lpt_renderer_read_radiance_owned).
+ * Rank 0 prints a checksum of the presented frame; it does not depend on N (the N-GPU image is the 1-GPU image bit for bit) — and the checksum of
+ * the same frame assembled by the HOST-SIDE GATHER: every rank writes its own pixels into one whole frame in host memory
+ * (lpt_renderer_read_radiance_owned).  In the N-process form that frame is POSIX shared memory behind lpt_host_frame_* (LPT_FRAME_NAME = "/name":
+ * rank 0 creates it BEFORE it publishes the id file, the others attach after reading the id; lpt_host_frame_barrier completes a frame).
  * Build: gcc -std=c11 -Iinclude examples/multi_gpu.c -Lloupiote_amd -lloupiote_hip -Wl,-rpath,$PWD/loupiote_amd -lm -o multi_gpu */
 #include <math.h>
 #include <stdio.h>
@@ -43,9 +45,12 @@ int main(int argc, char **argv) {
     lpt_comm *comm = NULL;
     lpt_renderer *r[64] = {0};
     const int n_local = multi_process ? 1 : world;
+    const char *frame_name = multi_process ? getenv("LPT_FRAME_NAME") : NULL;
+    lpt_host_frame *hframe = NULL;
     if (multi_process) {
         unsigned char id[LPT_COMM_ID_BYTES];
         if (rank == 0) {
+            if (frame_name) CHECK(lpt_host_frame_create(frame_name, W, H, (uint32_t)world, 0, &hframe));   /* shm + hipHostRegister; exists before the id does */
             CHECK(lpt_comm_unique_id(id));
             char tmp[1024];
             snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
@@ -58,6 +63,7 @@ int main(int argc, char **argv) {
             for (int tries = 0; tries < 600 && !(f = fopen(id_file, "rb")); ++tries) usleep(100000);
             if (!f || fread(id, 1, sizeof id, f) != sizeof id) { fprintf(stderr, "cannot read %s\n", id_file); return 1; }
             fclose(f);
+            if (frame_name) CHECK(lpt_host_frame_attach(frame_name, W, H, (uint32_t)world, 0, &hframe));
         }
         CHECK(lpt_comm_create(dev, id, rank, world, &comm));       /* ncclCommInitRank */
     }
@@ -77,16 +83,28 @@ int main(int argc, char **argv) {
         if (multi_process) CHECK(lpt_renderer_exchange(r[0], LPT_EXCHANGE_GATHER_TILES));   /* every rank, same order */
         else CHECK(lpt_renderer_exchange_local(r[0], n_local > 1 ? &r[1] : NULL, n_local - 1));
     }
+    /* The HOST-SIDE GATHER, for hosts that consume the frame on the CPU: no exchange on the GPUs — every rank writes its OWNED pixels straight into the one
+     * shared frame, each GPU its 1/N over its own PCIe link, and the frame barrier completes it (every rank; frame numbers count from 1). */
+    double sum_shared = -1.0;
+    if (hframe) {
+        float *frame = NULL;
+        CHECK(lpt_host_frame_ptr(hframe, &frame));
+        CHECK(lpt_renderer_read_radiance_owned(r[0], frame));
+        CHECK(lpt_host_frame_barrier(hframe, (uint32_t)rank, 1u, 60000u));
+        if (rank == 0) {
+            sum_shared = 0.0;
+            for (size_t i = 0; i < (size_t)W * H; ++i) sum_shared += frame[4 * i] + frame[4 * i + 1] + frame[4 * i + 2];
+        }
+        CHECK(lpt_host_frame_barrier(hframe, (uint32_t)rank, 2u, 60000u));   /* nobody unmaps (rank 0: unlinks) before rank 0 has read the frame */
+    }
     if (rank == 0) {
         float *img = (float *)malloc(sizeof(float) * 4 * (size_t)W * H);
         CHECK(lpt_renderer_read_radiance(r[0], img));               /* the presented frame: every rank's tiles */
         double sum = 0.0;
         size_t covered = 0;
         for (size_t i = 0; i < (size_t)W * H; ++i) { sum += img[4 * i] + img[4 * i + 1] + img[4 * i + 2]; covered += img[4 * i + 3] == 1.0f; }
-        /* The HOST-SIDE GATHER, for hosts that consume the frame on the CPU: no exchange — every rank writes its OWNED pixels straight into one
-         * whole-frame buffer in page-locked host memory (in an N-process job: a shared-memory segment each process maps and passes to
-         * lpt_host_register), each GPU its 1/N over its own PCIe link; a barrier of the host's own completes the frame. */
-        double sum_owned = -1.0;
+        /* the same gather inside ONE process: a page-locked buffer of the host's own (lpt_host_alloc), no barrier needed */
+        double sum_owned = sum_shared;
         if (!multi_process) {
             float *frame = NULL;
             CHECK(lpt_host_alloc(sizeof(float) * 4 * (size_t)W * H, (void **)&frame));
@@ -101,6 +119,7 @@ int main(int argc, char **argv) {
         free(img);
     }
     for (int k = 0; k < n_local; ++k) lpt_renderer_destroy(r[k]);
+    if (hframe) lpt_host_frame_destroy(hframe);
     if (comm) lpt_comm_destroy(comm);
     lpt_scene_gpu_destroy(sg);
     lpt_scene_destroy(scene);

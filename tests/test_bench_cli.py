@@ -84,7 +84,10 @@ def test_replayed_profile_figures_live_under_one_key_and_frac_fabric_rides_with_
     sys.path.insert(0, ROOT)
     import bench
     obj, traffic = bench.from_profiles_object(1.0)
-    assert set(obj) == {"what", "source", "traffic", "traffic_unit", "limits", "binding_limit"} and "NOT measured in this run" in obj["what"]
+    assert set(obj) == {"what", "source", "traffic", "traffic_unit", "limits", "binding_limit", "kernel_source_hash", "stale"} and "NOT measured in this run" in obj["what"]
+    # round 5: the profiles record the device code they were measured on; a changed kernel with un-refreshed profiles is flagged
+    assert obj["kernel_source_hash"]["this_tree"] == bench.kernel_source_hash() and len(obj["kernel_source_hash"]["this_tree"]) == 16
+    assert obj["stale"] is (obj["kernel_source_hash"]["profiles"] != obj["kernel_source_hash"]["this_tree"])
     assert traffic == obj["traffic"] and traffic > 1e9 and obj["source"]["traffic"].startswith("profiles/traffic.json")
     assert obj["binding_limit"]["name"] == "vector_memory_path" and 0 < obj["binding_limit"]["frac"] < 1
     frac, frac_fabric = bench.roofline_fractions(7990.0, traffic, 1.008)
@@ -93,6 +96,10 @@ def test_replayed_profile_figures_live_under_one_key_and_frac_fabric_rides_with_
     assert bench.roofline_fractions(7990.0, None, 1.0)[1] is None
     # the keys of the roofline object the line carries, as the source states them
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for key in ('"frac": rf_frac', '"frac_fabric": rf_frac_fabric', '"from_profiles": profiles_j', '"traffic": fabric_bytes', '"shard_emulation": shard_emulation'):
+    for key in ('"frac": rf_frac', '"frac_fabric": rf_frac_fabric', '"from_profiles": profiles_j', '"traffic": fabric_bytes', '"shard_emulation": shard_emulation',
+                '"frac_fetched": rf_frac_fetched', '"Grays_per_s": rays_per_launch', '"fixed_counts": fixed', '"exchange_forms": exchange_forms', '"stage_ms_per_rank": stage_ms_ranks'):
         assert key in src, key
+    # the fixed per-config counts of SURVEY 8d are committed with the fixtures and are what `frac` is computed from
+    fixed = bench.fixed_traversal_counts()
+    assert fixed is None or (10 < fixed["nodes_per_ray"] < 16 and 3 < fixed["tris_per_ray"] < 6 and 6 < fixed["shadow_nodes_per_ray"] < 12 and 1 < fixed["shadow_tris_per_ray"] < 3)
     assert '"limits": limits_j,' not in src.split('"roofline": {')[1].split('"from_profiles": profiles_j')[0]   # not beside the live figures any more

@@ -100,13 +100,33 @@ def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processe
 
 
 def test_host_side_gather_across_processes():
-    """`--exchange host`: no RCCL at all — the N processes write their owned pixels into ONE frame in POSIX shared memory (lpt_host_register +
-    lpt_renderer_read_radiance_owned) and a barrier on shared words completes it; the frame is the one-process frame bit for bit"""
+    """`--exchange host`: the timed region needs no RCCL at all — the N processes write their owned pixels into ONE frame in POSIX shared memory behind the C ABI
+    (lpt_host_frame_create / _attach, lpt_renderer_read_radiance_owned, lpt_host_frame_barrier: shm + hipHostRegister + progress words, no Python in the protocol);
+    the frame is the one-process frame bit for bit.  (Without the stand-in the extra RCCL legs of `exchange_forms` fail — real RCCL refuses two ranks on one
+    GPU — and are reported as errors: they must not take the line down.)"""
     one = _bench(["--no-extras"])
     for n in (2, 3):
         j = _bench(["--gpus", str(n), "--oversubscribe", "--exchange", "host", "--no-extras"])
         assert j["n_gpus"] == n and j["rccl"] is None and j["host_gather"]["frame_complete_on_rank0"] is True and j["host_gather"]["ranks"] == n
         assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"] and j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+        assert j["exchange_forms"]["host"]["timed_region"] is True and j["exchange_forms"]["host"]["frame_checksum"] > 0
+
+
+def test_one_run_times_all_three_exchange_forms(fake_rccl):
+    """an N>1 line carries `exchange_forms` {gather, reduce, host} -> {ms_per_frame, Mrays_s, frame_checksum} — the main form from the timed region, the
+    other two from 20 frames each in the same processes — with the three checksums equal, whichever form the timed region used; and the per-rank extremes
+    of every stage time (load imbalance of the interleaved tiles)"""
+    for main in ("gather", "host", "reduce"):
+        j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--exchange", main, "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+        ef = j["exchange_forms"]
+        assert ef["checksums_equal"] is True, ef
+        for form in ("gather", "reduce", "host"):
+            assert "error" not in ef[form], (main, form, ef[form])
+            assert ef[form]["ms_per_frame"] > 0 and ef[form]["Mrays_s"] > 0 and ef[form]["frame_checksum"] == ef[main]["frame_checksum"]
+            assert ef[form]["timed_region"] is (form == main)
+        sr = j["stage_ms_per_rank"]
+        assert "shading" in sr or "path" in sr
+        assert all(v["max"] >= v["min"] >= 0.0 and 0 <= v["rank_of_max"] < 2 for v in sr.values())
 
 
 def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):

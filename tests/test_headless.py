@@ -76,10 +76,13 @@ def test_plain_c_multi_gpu_example_gives_the_same_frame_for_any_rank_count(tmp_p
         assert j["covered"] == 203 * 117 and j["ranks"] == n
         assert j["host_gather_checksum"] == j["checksum"]      # every rank's own pixels written straight into one host frame: the same frame
         sums.append(j["checksum"])
-    env = dict(os.environ, LPT_RANK="0", LPT_WORLD="1", LPT_ID_FILE=str(tmp_path / "rccl.id"))
+    # one rank of a "multi-process" job: the RCCL id through a file, and the host-side gather through the shared frame of the C ABI (lpt_host_frame_*)
+    env = dict(os.environ, LPT_RANK="0", LPT_WORLD="1", LPT_ID_FILE=str(tmp_path / "rccl.id"), LPT_FRAME_NAME="/lpt_example_%d" % os.getpid())
     p = subprocess.run([exe, glb, "1", "203", "117", "3"], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr
     j = json.loads(p.stdout.strip().splitlines()[-1])
     assert j["multi_process"] == 1 and os.path.getsize(str(tmp_path / "rccl.id")) == 128
+    assert j["host_gather_checksum"] == j["checksum"]          # through lpt_host_frame_create / _ptr / _barrier / _destroy
+    assert not os.path.exists("/dev/shm/lpt_example_%d" % os.getpid())
     sums.append(j["checksum"])
     assert len(set(sums)) == 1, sums

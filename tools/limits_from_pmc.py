@@ -20,6 +20,20 @@ import re
 import sys
 from collections import defaultdict
 
+import hashlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the device code the counters were measured on: bench.py compares it with the tree it runs from and marks the replayed
+    figures `stale` when they differ (the same function lives in bench.py)"""
+    h = hashlib.sha256()
+    for f in ("kernels.h", "pool_kernels.h", "device_math.h"):
+        h.update(open(os.path.join(ROOT, "loupiote_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 SIMDS = 256 * 4
 FAST_RATE, SLOW_RATE = 0.40, 0.234  # wave-instructions per REAL shader cycle per SIMD at 8 waves/SIMD (valu_rate under rocprofv3: profiles/r03_valu_rate_real_clock.txt)
@@ -62,7 +76,7 @@ def main(tag, out):
             bench = {}
     traffic = {"_comment": "fabric-side bytes per launch from rocprofv3 --pmc (separate passes, tools/profile.sh): FETCH_SIZE (KiB; gfx950 tallies 128-B requests at "
                            "64 B, so doubled, MI355X_MICROARCH.md §HBM) + WRITE_SIZE (KiB).  The BVH is L2 / Infinity-Cache resident: this is fabric traffic, not "
-                           "necessarily DRAM traffic.", "round": tag, "source": "profiles/traffic.json@" + tag}
+                           "necessarily DRAM traffic.", "round": tag, "source": "profiles/traffic.json@" + tag, "kernel_source_hash": kernel_source_hash()}
     for k, key in (("k_trace<false>", "k_trace"), ("k_shade<false>", "k_shade")):
         f, w = per_launch(k, "FETCH_SIZE"), per_launch(k, "WRITE_SIZE")
         if f is not None and w is not None:
@@ -72,7 +86,7 @@ def main(tag, out):
             traffic[key + "_launches_profiled"] = len(launches[(k, "FETCH_SIZE")])
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 
-    lim = {"round": tag, "source": "profiles/limits.json@" + tag, "kernel": "k_trace<false>", "clock_hz": CLOCK_HZ}
+    lim = {"round": tag, "source": "profiles/limits.json@" + tag, "kernel": "k_trace<false>", "clock_hz": CLOCK_HZ, "kernel_source_hash": kernel_source_hash()}
     k = "k_trace<false>"
     avg_ns = solo.get(k, (None, 0))[0]
     if avg_ns:
