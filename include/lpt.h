@@ -562,7 +562,7 @@ typedef enum lpt_option {
     LPT_OPT_OCC_CELL_MILLI = 11,    /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
     LPT_OPT_STEP_BUDGET = 12,       /* per-bounce traversal launches: a ray not finished after this many steps is dropped by the per-lane kernel and traced
                                      * again by a whole wave (k_trace_coop: eight lanes per node), so that the one ray in 10^5 that needs hundreds of steps
-                                     * does not set the duration of the launch; default 48, 0 = off */
+                                     * does not set the duration of the launch; default 48, 0 = off.  Not applied while lpt_renderer_enable_stats is on */
     LPT_OPT_BUDGET_RAYS = 13,       /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
                                      * value applies the budget to every wavefront up to it) */
     LPT_OPT_PACKET_QUADS = 14,      /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
@@ -597,7 +597,9 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out);
 int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *shadow, uint32_t cap);
 int lpt_renderer_reset_ray_counts(lpt_renderer *r);
 /* new, stats enabled only: traversal steps per ray over the per-bounce traversal launches of the LAST wavefront — the maximum (the longest
- * ray of a launch sets its duration) and a histogram by power of two (hist12[k]: 2^k <= steps < 2^(k+1)).  Blocking. */
+ * ray of a launch sets its duration, docs/ROUNDS.md §5.5) and a histogram by power of two (hist12[k]: 2^k <= steps < 2^(k+1)).  Blocking.
+ * The stats kernels run WITHOUT the step budget (LPT_OPT_STEP_BUDGET): every ray is traced to its end by the per-lane kernel, so the histogram, the
+ * maximum and the nodes / triangles per ray are those of complete traversals, whatever the option says. */
 int lpt_renderer_get_step_histogram(lpt_renderer *r, uint32_t *max_steps, uint32_t *hist12);
 /* count BVH nodes visited / triangles tested per ray (slower kernel variant) */
 int lpt_renderer_enable_stats(lpt_renderer *r, int flag);

@@ -173,6 +173,7 @@ constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to th
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 450000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over against the per-bounce launches WITH their step budget
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
+constexpr uint32_t kCoopWavesPerCu = 32u;   // k_trace_coop's grid: a wave per straggler, most waves find none and leave (8 / 4 per CU: the same 2.90 ms per 1/8-shard frame, round 5)
 constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
@@ -1625,7 +1626,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
     const bool denoise = r->mode != LPT_BLIT_PATHTRACE;
     // the lane (Wavefront) this call's rays live in: consecutive calls take the lanes in turn; the denoising modes
     // carry frame-to-frame state (G-buffer ping-pong, motion) and stay on lane 0
-    const bool split = r->n_lanes > 1;           // the wavefront runs on the lane's own stream
+    const bool split = r->n_lanes > 1;           // the wavefront runs on the lane's own stream (a single wavefront on the renderer's own stream instead: 2.89 against 2.90 ms per 1/8-shard frame, round 5)
     const int lane = (denoise || !split) ? 0 : (int)(r->lane_rr++ % (uint32_t)r->n_lanes);
     {
         int st = ensure_lane(r, lane);
@@ -1737,8 +1738,8 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
             if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
                 const size_t clds = sizeof(uint32_t) * coop_stack_entries(r->sg->stats.max_depth);
-                if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * 32u), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
-                else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * 32u), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+                if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * kCoopWavesPerCu), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
+                else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * kCoopWavesPerCu), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
             }
             stage_end(r, s);
         };

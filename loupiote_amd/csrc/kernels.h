@@ -502,6 +502,9 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
         if (ray_triangle(r0, r1, r2, rs.o, rs.d, rs.best.t, t, u, v)) {
             const uint32_t prim = sc.leaf_prim[ti];
             if (t < rs.best.t || prim < rs.best.prim) { rs.best.t = t; rs.best.u = u; rs.best.v = v; rs.best.prim = prim; }
+            // the occluder's leaf slot, for the occluder-cache probe of the stats kernels (an any-hit ray's v is not read).  Round 5: only ray_step_pipe did this,
+            // so `--opt pipe_rays=0` with stats on fed the probe a barycentric's bit pattern as a leaf slot: an out-of-bounds read (a GPU memory fault at bench size)
+            if (STATS && ANY) rs.best.v = __uint_as_float(ti);
             if (ANY) return true;
         }
     }

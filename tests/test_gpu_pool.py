@@ -128,3 +128,46 @@ def test_pool_in_the_denoising_modes_writes_the_same_g_buffer(device, cornell):
         outs.append((g.tobytes(), m.tobytes(), rad.tobytes(), hist.tobytes(), r.read_pixels().tobytes()))
         r.close()
     assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+def test_stats_kernels_of_every_traversal_variant_run_clean(tmp_path):
+    """round 5 regression: with stats on, the occluder-cache probe of k_trace reads the occluder's leaf slot out of an any-hit ray's `v` — which only the
+    one-round-trip step wrote.  `pipe_rays = 0` + stats (what `bench.py --opt pipe_rays=0` does in its stats frame) indexed the triangle array with a
+    barycentric's bit pattern: a GPU memory fault at bench size.  Every variant in its own process (a fault kills the process, not the suite); the stats
+    frame must equal the plain frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import loupiote_amd as lp
+from loupiote_amd import scenes, testing as T
+opts = json.loads(sys.argv[1])
+dev = lp.Device(0)
+desc = scenes.synthetic_atrium(texture_size=64)
+sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), dev)
+pr = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+sums = []
+for stats in (0, 1):
+    r = lp.Renderer(dev, (960, 544)); r.downsample_factor = 1.0; r.resize(dev, sg, pr, (960, 544)); r.set_max_bounces(8); r.set_vfov(T.VFOV)
+    for k, v in opts.items(): r.set_option(k, v)
+    r.enable_stats(bool(stats))
+    r.reset_accumulation(); r.accumulate = True
+    r.raytrace_n(view, 4)
+    img = r.read_radiance()
+    c = r.ray_counts()
+    sums.append((float(np.float64(img[..., :3].sum())), int(c.closest), int(c.shadow), int(c.nodes), int(c.shadow_nodes)))
+    r.close()
+print(json.dumps(sums))
+''' % root
+    for opts in ({"pipe_rays": 0}, {"pipe_rays": 0, "merge_trace": 0}, {}, {"path_rays": 0x7FFFFFFF}, {"path_rays": 0, "pool_rays": 0x7FFFFFFF}, {"pipe_rays": 0, "step_budget": 8, "budget_rays": 0x7FFFFFFF}):
+        p = subprocess.run([sys.executable, "-c", code, json.dumps(opts)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (opts, p.stderr[-1500:])
+        plain, stats = json.loads(p.stdout.strip().splitlines()[-1])
+        assert plain[:3] == stats[:3], opts                # the same frame and ray counts
+        assert plain[3] == 0 and stats[3] > 0 and (stats[4] > 0 or opts.get("merge_trace") == 0), (opts, plain, stats)   # nodes are counted by the stats kernels only

@@ -14,6 +14,7 @@ r.resize(dev, sg, pr, (1920, 1080))
 r.set_max_bounces(8)
 r.set_vfov(T.VFOV)
 r.set_option("path_rays", 0)
+r.set_option("step_budget", 0)   # a ray dropped at the budget would be missing from the histogram (the stats kernels run without it anyway since round 5)
 if shard > 1:
     r.set_shard(0, shard, 32, 8)
     r.set_resources(dev, sg, pr)
