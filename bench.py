@@ -75,6 +75,7 @@ def parse_args(argv=None):
                     help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv), the dense ncclReduce of the accumulation buffer, or "
                          "`host`: no exchange on the GPUs — every rank writes its owned pixels straight into ONE shared-memory frame (lpt_renderer_read_radiance_owned; "
                          "each GPU's 1/N over its own PCIe link), completed by a host-side barrier")
+    ap.add_argument("--no-exchange-forms", action="store_true", help="N>1: skip the legs that time the two exchange forms the timed region did not use (tests that do not look at them)")
     ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
     ap.add_argument("--root-weight", type=int, default=0, help="N>1: tile-ownership weight of rank 0 against 8 for every other rank (lpt_renderer_set_shard_weighted): "
@@ -804,63 +805,6 @@ def run(args):
         for rr in rs:
             rr.close()
 
-    # ================================================================== N>1: the three exchange forms in ONE run (SURVEY 8e: "implement ncclReduce first, then the compact
-    # variant, and report both"; the host-side gather is the third).  The timed region above used `--exchange`; the other two get 20 frames each here, on fresh
-    # renderers (RCCL forms: the calibrated tile weights if the main form calibrated them, else equal shares; host form: equal shares), same span, max over ranks.
-    exchange_forms = None
-    lazy_comms = []
-    if use_dist and (world > 1 or args.force_dist) and not args.emulate_shard and not denoising:
-        main_form = args.exchange
-        exchange_forms = {"what": "ms per frame and Mrays/s of the SAME frame ended by each exchange form, one process per GPU: gather = owned tiles by grouped ncclSend/ncclRecv "
-                                  "+ read_radiance on rank 0; reduce = ncclReduce(sum) of the whole radiance buffer + read_radiance on rank 0; host = every rank writes its own pixels "
-                                  "into one shared host frame (lpt_host_frame_*), no exchange on the GPUs.  `%s` is the timed region of this line, the others 20 frames after 3 warm-up "
-                                  "frames.  frame_checksum = sum of the RGB of the FIRST frame of a fresh renderer ended by that form, on rank 0 (a renderer's seed counter never "
-                                  "rewinds, so only frames of equal index compare) — the three must be equal" % main_form,
-                          main_form: {"ms_per_frame": elapsed / n_frames * 1e3, "Mrays_s": (closest + shadow) / elapsed / 1e6, "frames": n_frames, "timed_region": True}}
-        for form in ("gather", "reduce", "host"):
-            try:
-                if form == "host":
-                    if shared is None:
-                        raise RuntimeError("no shared host frame (one rank)")
-                    rr = make_renderer(None, lanes=args.lanes or None, host_form=True, wts=None)
-                else:
-                    if not comms and not lazy_comms:   # the main form was `host`: RCCL comes up only now (and a failure here cannot take the headline down)
-                        box = [lp.Comm.unique_id() if rank == 0 else None]
-                        dist.broadcast_object_list(box, src=0)
-                        lazy_comms.append(lp.Comm(dev, box[0], rank, world))
-                    rr = make_renderer((comms or lazy_comms)[0], lanes=args.lanes or None, host_form=False)
-                span_frame(rr, form)    # the first frame of a fresh renderer: the one whose checksum compares across the forms
-                ck = float(np.float64(last["img"][..., :3].sum())) if rank == 0 else None
-                dist.barrier()          # the host form's image IS the shared frame: read before anybody renders into it again
-                if form == main_form:
-                    exchange_forms[form]["frame_checksum"] = ck      # its times are the timed region's
-                else:
-                    for _ in range(2):
-                        span_frame(rr, form)
-                    rr.reset_ray_counts()
-                    fence([rr])
-                    t1 = time.perf_counter()
-                    for _ in range(20):
-                        span_frame(rr, form)
-                    fence([rr])
-                    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-                    cc = rr.ray_counts()
-                    ry = torch.tensor([float(cc.closest + cc.shadow)], dtype=torch.float64)
-                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                    dist.all_reduce(ry, op=dist.ReduceOp.SUM)
-                    exchange_forms[form] = {"ms_per_frame": float(dt.item()) / 20 * 1e3, "Mrays_s": float(ry.item()) / float(dt.item()) / 1e6, "frame_checksum": ck, "frames": 20, "timed_region": False}
-                rr.close()
-            except Exception as e:   # noqa: BLE001 - an extra leg must not cost the line
-                if form == main_form:
-                    exchange_forms[form]["error"] = "%s: %s" % (type(e).__name__, e)
-                else:
-                    exchange_forms[form] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0:
-            cks = [v.get("frame_checksum") for k, v in exchange_forms.items() if isinstance(v, dict) and "frame_checksum" in v]
-            exchange_forms["checksums_equal"] = bool(len(cks) >= 2 and all(c == cks[0] for c in cks))
-            if not exchange_forms["checksums_equal"]:
-                print("bench.py: the exchange forms do not end in the same frame: %r" % ({k: v for k, v in exchange_forms.items() if k != "what"},), file=sys.stderr)
-
     host_gather_j = None
     if host_gather:
         host_gather_j = {"what": "no exchange on the GPUs: every rank wrote its owned pixels of the mean radiance into ONE shared-memory frame (lpt_renderer_read_radiance_owned), "
@@ -917,7 +861,7 @@ def run(args):
             "shard_emulation": shard_emulation,
             "rccl": rccl,
             "host_gather": host_gather_j,
-            "exchange_forms": exchange_forms,
+            "exchange_forms": None,      # filled in below: the legs run after the line is assembled (a watchdog prints it if they hang)
             "stage_ms_per_rank": stage_ms_ranks,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": fixed_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": rf_frac,
@@ -960,6 +904,90 @@ def run(args):
             out["cpu_baseline"] = cpu_baseline(desc, view, effective_cpus(), T)
         elif world > 1:
             out["cpu_baseline"] = None
+    # The legs below run RCCL calls that have never executed with more than one rank anywhere (ncclReduce; ncclSend / ncclRecv when the main form was `host`): a hang
+    # there must not cost the line.  A watchdog on every rank: after 180 s rank 0 prints the line it has (exchange_forms = the legs finished so far + the
+    # timeout) and every rank leaves at once.
+    import threading
+    wd_state = {"done": False}
+
+    def wd_bail():
+        if wd_state["done"]:
+            return
+        if rank == 0 and out is not None:
+            out["exchange_forms"] = dict(exchange_forms or {}, error="timed out after 180 s: the remaining legs did not finish")
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    watchdog = threading.Timer(180.0, wd_bail)
+    watchdog.daemon = True
+    if use_dist and (world > 1 or args.force_dist):
+        watchdog.start()
+    # ================================================================== N>1: the three exchange forms in ONE run (SURVEY 8e: "implement ncclReduce first, then the compact
+    # variant, and report both"; the host-side gather is the third).  The timed region above used `--exchange`; the other two get 20 frames each here, on fresh
+    # renderers (RCCL forms: the calibrated tile weights if the main form calibrated them, else equal shares; host form: equal shares), same span, max over ranks.
+    exchange_forms = None
+    lazy_comms = []
+    if use_dist and (world > 1 or args.force_dist) and not args.emulate_shard and not denoising and not args.no_exchange_forms:
+        main_form = args.exchange
+        exchange_forms = {"what": "ms per frame and Mrays/s of the SAME frame ended by each exchange form, one process per GPU: gather = owned tiles by grouped ncclSend/ncclRecv "
+                                  "+ read_radiance on rank 0; reduce = ncclReduce(sum) of the whole radiance buffer + read_radiance on rank 0; host = every rank writes its own pixels "
+                                  "into one shared host frame (lpt_host_frame_*), no exchange on the GPUs.  `%s` is the timed region of this line, the others 20 frames after 3 warm-up "
+                                  "frames.  frame_checksum = sum of the RGB of the FIRST frame of a fresh renderer ended by that form, on rank 0 (a renderer's seed counter never "
+                                  "rewinds, so only frames of equal index compare) — the three must be equal" % main_form,
+                          main_form: {"ms_per_frame": elapsed / n_frames * 1e3, "Mrays_s": (closest + shadow) / elapsed / 1e6, "frames": n_frames, "timed_region": True}}
+        for form in ("gather", "reduce", "host"):
+            try:
+                if form == "host":
+                    if shared is None:
+                        raise RuntimeError("no shared host frame (one rank)")
+                    rr = make_renderer(None, lanes=args.lanes or None, host_form=True, wts=None)
+                else:
+                    if not comms and not lazy_comms:   # the main form was `host`: RCCL comes up only now (and a failure here cannot take the headline down)
+                        box = [lp.Comm.unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(box, src=0)
+                        lazy_comms.append(lp.Comm(dev, box[0], rank, world))
+                    rr = make_renderer((comms or lazy_comms)[0], lanes=args.lanes or None, host_form=False)
+                span_frame(rr, form)    # the first frame of a fresh renderer: the one whose checksum compares across the forms
+                ck = float(np.float64(last["img"][..., :3].sum())) if rank == 0 else None
+                dist.barrier()          # the host form's image IS the shared frame: read before anybody renders into it again
+                if form == main_form:
+                    exchange_forms[form]["frame_checksum"] = ck      # its times are the timed region's
+                else:
+                    for _ in range(2):
+                        span_frame(rr, form)
+                    rr.reset_ray_counts()
+                    fence([rr])
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        span_frame(rr, form)
+                    fence([rr])
+                    dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+                    cc = rr.ray_counts()
+                    ry = torch.tensor([float(cc.closest + cc.shadow)], dtype=torch.float64)
+                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+                    exchange_forms[form] = {"ms_per_frame": float(dt.item()) / 20 * 1e3, "Mrays_s": float(ry.item()) / float(dt.item()) / 1e6, "frame_checksum": ck, "frames": 20, "timed_region": False}
+                rr.close()
+            except Exception as e:   # noqa: BLE001 - an extra leg must not cost the line
+                if form == main_form:
+                    exchange_forms[form]["error"] = "%s: %s" % (type(e).__name__, e)
+                else:
+                    exchange_forms[form] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            cks = [v.get("frame_checksum") for k, v in exchange_forms.items() if isinstance(v, dict) and "frame_checksum" in v]
+            exchange_forms["checksums_equal"] = bool(len(cks) >= 2 and all(c == cks[0] for c in cks))
+            if not exchange_forms["checksums_equal"]:
+                print("bench.py: the exchange forms do not end in the same frame: %r" % ({k: v for k, v in exchange_forms.items() if k != "what"},), file=sys.stderr)
+
+    wd_state["done"] = True
+    watchdog.cancel()
+    if out is not None:
+        out["exchange_forms"] = exchange_forms
     if use_dist:
         dist.barrier()
     if shared is not None:

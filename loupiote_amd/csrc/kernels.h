@@ -411,12 +411,7 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
         const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
         if (STATS) n_nodes++;
         const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;
-#ifdef LPT_EXP_NOMUL
-        const uint32_t oinv2 = rs.oinv | (rs.oinv << 8);
-        const uint32_t oinv4 = oinv2 | (oinv2 << 16);   // = oinv * 0x01010101 without the quarter-rate v_mul_lo_u32
-#else
-        const uint32_t oinv4 = rs.oinv * 0x01010101u;
-#endif
+        const uint32_t oinv4 = rs.oinv * 0x01010101u;   // (this and the other two v_mul_lo_u32 of a visit as shifts / sub: no change, profiles/r05_experiments_ab.txt E)
         // t(q) = q * a + b per axis; a is exact (power-of-two step times 1/d), b carries three roundings.
         // |error of the computed t| <= 2^-24 * (4|b| + 510|a|), so widening b by eps = 2^-21 * (|b| + 255|a|)
         // towards the outside on both ends keeps the test conservative wherever the ray starts.
@@ -438,12 +433,7 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
         for (int half = 0; half < 2; ++half) {
             const uint32_t meta4 = half ? n1.w : n1.z;
             const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-#ifdef LPT_EXP_NOMUL
-            const uint32_t inner1 = is_inner4 >> 4;
-            const uint32_t inner_mask4 = (inner1 << 8) - inner1;   // = inner1 * 0xFF modulo 2^32
-#else
             const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
-#endif
             const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
             const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
             const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;

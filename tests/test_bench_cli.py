@@ -97,7 +97,7 @@ def test_replayed_profile_figures_live_under_one_key_and_frac_fabric_rides_with_
     # the keys of the roofline object the line carries, as the source states them
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"frac": rf_frac', '"frac_fabric": rf_frac_fabric', '"from_profiles": profiles_j', '"traffic": fabric_bytes', '"shard_emulation": shard_emulation',
-                '"frac_fetched": rf_frac_fetched', '"Grays_per_s": rays_per_launch', '"fixed_counts": fixed', '"exchange_forms": exchange_forms', '"stage_ms_per_rank": stage_ms_ranks'):
+                '"frac_fetched": rf_frac_fetched', '"Grays_per_s": rays_per_launch', '"fixed_counts": fixed', 'out["exchange_forms"] = exchange_forms', '"stage_ms_per_rank": stage_ms_ranks'):
         assert key in src, key
     # the fixed per-config counts of SURVEY 8d are committed with the fixtures and are what `frac` is computed from
     fixed = bench.fixed_traversal_counts()

@@ -18,6 +18,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "1", "--warmup", "1", "--frames-per-step", "3", "--width", "480", "--height", "270", "--texture-size", "64", "--no-cpu-baseline"]
+NOXF = ["--no-exchange-forms"]   # the legs that time the other two exchange forms: only the tests that look at them pay for them
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +52,7 @@ def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
     one = _bench(["--no-extras"])
     assert one["n_gpus"] == 1 and one["config"]["frame_complete"] is True
     for n, mode in ((2, "gather"), (3, "reduce"), (3, "gather")):
-        j = _bench(["--gpus", str(n), "--oversubscribe", "--root-weight", "8", "--exchange", mode, "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+        j = _bench(["--gpus", str(n), "--oversubscribe", "--root-weight", "8", "--exchange", mode, "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
         assert j["n_gpus"] == n and j["rccl"]["rccl_nranks"] == n and j["rccl"]["mode"] == mode
         assert j["rccl"]["exchange_frame_complete_on_rank0"] is True
         assert len(j["rccl"]["per_rank_rays"]) == n and all(r > 0 for r in j["rccl"]["per_rank_rays"])
@@ -89,7 +90,7 @@ def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processe
     processes (BASELINE config 5's form): the filter inputs travel after every call, rank 0 filters, its tile weight is calibrated with
     the filter in the frame (VERDICT r03 #4 iv) — the presented frame equals the one-process frame bit for bit."""
     one = _bench(["--no-extras"])
-    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--group-bracket", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--group-bracket", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     assert j["rccl"]["exchange_frame_complete_on_rank0"] is True and j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
     t1 = _bench(["--blit-mode", "temporal", "--no-extras", "--no-shard-emulation"])
     for extra in (["--root-weight", "8"], ["--group-bracket"], ["--exchange", "reduce"]):
@@ -106,10 +107,11 @@ def test_host_side_gather_across_processes():
     GPU — and are reported as errors: they must not take the line down.)"""
     one = _bench(["--no-extras"])
     for n in (2, 3):
-        j = _bench(["--gpus", str(n), "--oversubscribe", "--exchange", "host", "--no-extras"])
+        j = _bench(["--gpus", str(n), "--oversubscribe", "--exchange", "host", "--no-extras"] + (NOXF if n == 3 else []))
         assert j["n_gpus"] == n and j["rccl"] is None and j["host_gather"]["frame_complete_on_rank0"] is True and j["host_gather"]["ranks"] == n
         assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"] and j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
-        assert j["exchange_forms"]["host"]["timed_region"] is True and j["exchange_forms"]["host"]["frame_checksum"] > 0
+        if n == 2:
+            assert j["exchange_forms"]["host"]["timed_region"] is True and j["exchange_forms"]["host"]["frame_checksum"] > 0
 
 
 def test_one_run_times_all_three_exchange_forms(fake_rccl):
@@ -130,14 +132,14 @@ def test_one_run_times_all_three_exchange_forms(fake_rccl):
 
 
 def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):
-    j = _bench(["--gpus", "2", "--oversubscribe", "--throughput", "--pipeline", "2"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    j = _bench(["--gpus", "2", "--oversubscribe", "--throughput", "--pipeline", "2"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     r = j["rccl"]
     assert r["rccl_nranks"] == 2 and r["communicators_per_rank"] == 3 and r["exchange_frame_complete_on_rank0"] is True
     assert len(r["tile_weights"]) == 2 and 1 <= r["tile_weights"][0] <= 8 and r["tile_weights"][1] in (1, 8)
     assert r["tile_weight_calibration"]["rank0_extra_ms"] >= 0.0
     assert j["throughput"]["communicators"] == 2 and j["throughput"]["value"] > 0 and j["latency_ms"]["median"] > 0
     # a forced weight: rank 0 traces 3/11 of the tiles
-    k = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "3", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})
+    k = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "3", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     assert k["rccl"]["tile_weights"] == [3, 8] and k["rccl"]["exchange_frame_complete_on_rank0"] is True
     a, b = k["rccl"]["per_rank_rays"]
     assert 0.2 < a / (a + b) < 0.35
