@@ -118,6 +118,42 @@ def test_protocol_noops_and_default_downsample(device, cornell_glb):
     r.close(); sg.close()
 
 
+def test_destroying_a_scene_or_probe_detaches_the_renderers_bound_to_it(device, cornell_glb):
+    """the C renderer keeps the scene / probe pointers it was handed; a host that destroys them first (a Rust `drop(scene_gpu)` before the
+    renderer's) must not leave it dangling.  lpt_scene_gpu_destroy / lpt_probe_destroy submit what is recorded, wait, and DETACH every renderer still
+    bound: its next raytrace() is the no-op of a renderer without resources (renderer.rs:403-407), a dropped probe becomes the 1x1 default (:693-696)."""
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    scene = lp.Scene()
+    lp.loaders.load_gltf(cornell_glb, scene)
+    scene.set_light(0, T.cornell_light())
+    sg = lp.SceneGPU.new_from_scene(scene, device)
+    pr = lp.ProbeGPU(device, T.CORNELL_PROBE, 1, 1)
+    r = lp.Renderer(device, (128, 64))
+    r.downsample_factor = 1.0
+    r.resize(device, sg, pr, (128, 64))
+    r.set_max_bounces(4)
+    r.accumulate = True
+    r.raytrace(view)
+    r.raytrace(view)                      # recorded, not yet submitted
+    pr.close()                            # submits the two calls (they saw the probe), then detaches it
+    with_probe = r.read_radiance().copy()
+    assert with_probe[..., :3].sum() > 0 and r.frame_state()[0] == 3
+    r.raytrace(view)                      # traces against the default (black) probe now: still a frame
+    r.read_radiance()
+    n_before = r.submission_stats()[1]
+    sg.close()                            # the scene goes: the renderer is left without resources
+    r.raytrace(view)                      # a no-op, not a use-after-free
+    r.raytrace(view)
+    img = r.read_radiance()
+    assert np.all(np.isfinite(img)) and r.submission_stats()[1] == n_before        # no wavefront was launched
+    sg2 = lp.SceneGPU.new_from_scene(scene, device)
+    r.set_resources(device, sg2, None)    # bound again: frame_count back to 1 (:724), frames trace again
+    r.accumulate = True
+    r.raytrace(view)
+    assert r.read_radiance()[..., :3].sum() > 0 and r.submission_stats()[1] == n_before + 1
+    r.close(); sg2.close()
+
+
 def test_lifecycle_does_not_leak_device_memory(device, cornell_glb):
     """create / resize / render / destroy in a loop: free device memory returns to where it started"""
     import torch
