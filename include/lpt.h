@@ -571,7 +571,9 @@ typedef enum lpt_option {
                                      * launch as a CU-local POOL of trace and shade work (k_pool, round 5): a path is a record that the waves of a block
                                      * hand to each other through rings in LDS — any wave's idle lanes take the next ray to trace, a wave without rays in
                                      * flight shades 64 hits of one kind with all its lanes; no chip-wide barrier per bounce (renderer.rs:484-509) and no
-                                     * lane that waits for its own wave's shading batch.  0: never */
+                                     * lane that waits for its own wave's shading batch.  0 (default): never — bit-identical but measured slower than the per-bounce
+                                     * launches at every size (every wave carries the shading body's registers).  A tree so deep that the block's traversal stacks
+                                     * and rings exceed the CU's 160 KB of LDS takes the per-bounce launches whatever this says */
     LPT_OPT_POOL_SHADERS = 16,      /* pool kernel: waves of a block that prefer shading to tracing (default 2) */
     LPT_OPT_POOL_ENTRIES = 17,      /* pool kernel: path records per block, 0 (default: 256 per wave of a block) or a power of two in 256..32768 */
     LPT_OPT_POOL_WAVES = 18,        /* pool kernel: waves per block, 4 / 8 / 16 (default 8: two blocks per CU) */
