@@ -43,6 +43,7 @@ struct lpt_device {
     int compute_units = 0;
     char name[128] = {0};
     std::vector<lpt_renderer *> renderers;   // live renderers of this device: scene / probe edits submit their recorded calls first
+    bool pool_attr_set = false;              // k_pool's dynamic-LDS attribute has been raised on this device (hipFuncSetAttribute is per device)
 };
 
 // one RCCL communicator rank (frame exchange); created by lpt_comm_create
@@ -1789,13 +1790,12 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             }
             PoolArgs pa{wf.pool_slab, pool_entries, pool_trace_cap, std::min(r->pool_shaders, r->pool_waves), r->pool_refill, 256u, r->err_dev};
             const float4 *h0 = packet ? wf.hits : (const float4 *)nullptr;
-            static bool attr_set = false;
-            if (!attr_set) {   // more than 64 KB of dynamic LDS needs the attribute
+            if (!r->dev->pool_attr_set) {   // more than 64 KB of dynamic LDS needs the attribute
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
+                r->dev->pool_attr_set = true;
             }
             const dim3 pg(blocks), pb(64u * r->pool_waves);
             if (denoise) {
