@@ -10,7 +10,8 @@
 // Each word sits on its own 64-byte line.  Barrier of frame `no` (1, 2, 3, ... — the caller's frame counter, the same on every rank):
 // a rank stores `no` into its word (release); rank 0 waits until every word is >= no, stores `no` into the "all arrived" word and wakes
 // the sleepers; the others wait for that word.  Waiting = a bounded run of pause-spins (the barrier closes within microseconds of the
-// last rank's arrival in the normal case), then futex sleeps on the word with the caller's timeout.
+// last rank's arrival in the normal case), then futex sleeps with the caller's timeout: the others on the "all arrived" word, rank 0 on the word of the
+// rank it is waiting for (it leaves a note first, so that the arriving rank knows to wake it).
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -122,7 +123,10 @@ int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, 
     if (!f || rank >= f->world || !frame_no) return fail(LPT_ERR_INVALID_ARG, "lpt_host_frame_barrier: bad rank, or frame number 0 (frames count from 1)");
     Line *ln = f->lines();
     std::atomic<uint32_t> &all = ln[f->world].word;
-    ln[rank].word.store(frame_no, std::memory_order_release);
+    // rank 0's "I sleep on word q" note, in its own line's padding: an arriving rank wakes it only then (no syscall per rank and frame in the normal case)
+    std::atomic<uint32_t> &sleeping_on = *reinterpret_cast<std::atomic<uint32_t> *>(&ln[0].pad[0]);   // 0 = awake, q + 1 = asleep on rank q's word
+    ln[rank].word.store(frame_no, std::memory_order_seq_cst);
+    if (rank != 0u && sleeping_on.load(std::memory_order_seq_cst) == rank + 1u) futex(&ln[rank].word, FUTEX_WAKE, 1, nullptr);
     const double t_end = now_ms() + (double)timeout_ms;
     // serial numbers compare modulo 2^32: "word >= frame_no"
     auto reached = [frame_no](uint32_t v) { return (int32_t)(v - frame_no) >= 0; };
@@ -130,13 +134,22 @@ int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, 
         for (uint32_t q = 1; q < f->world; ++q) {
             uint32_t spins = 0;
             for (;;) {
-                const uint32_t v = ln[q].word.load(std::memory_order_acquire);
+                uint32_t v = ln[q].word.load(std::memory_order_acquire);
                 if (reached(v)) break;
                 if (++spins < 20000u) { __builtin_ia32_pause(); continue; }
                 const double left = t_end - now_ms();
                 if (left <= 0.0) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: rank %u did not reach frame %u within %u ms", q, frame_no, timeout_ms);
-                timespec ts{0, 200000};   // the arriving ranks do not wake rank 0 (one syscall less per rank and frame): short sleeps
-                nanosleep(&ts, nullptr);
+                // sleep ON rank q's word: say so first, look again (the store / load pairs on both sides are sequentially consistent: either rank q sees the note
+                // and wakes us, or we see its word), then wait — woken the moment rank q arrives, not at the end of a polling slice
+                sleeping_on.store(q + 1u, std::memory_order_seq_cst);
+                v = ln[q].word.load(std::memory_order_seq_cst);
+                if (!reached(v)) {
+                    timespec ts;
+                    const double slice = left < 50.0 ? left : 50.0;
+                    ts.tv_sec = 0; ts.tv_nsec = (long)(slice * 1e6);
+                    futex(&ln[q].word, FUTEX_WAIT, v, &ts);
+                }
+                sleeping_on.store(0u, std::memory_order_seq_cst);
             }
         }
         all.store(frame_no, std::memory_order_release);

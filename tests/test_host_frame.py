@@ -94,3 +94,29 @@ def test_without_host_only_the_segment_must_be_registered_with_a_device():
     with pytest.raises(lp.Error):
         lp.HostFrame.create(name, 16, 8, 2)
     assert not os.path.exists("/dev/shm" + name)
+
+
+def _late(name, world, delay_s, q):
+    f = lp.HostFrame.attach(name, 8, 8, world, host_only=True)
+    time.sleep(delay_s)
+    t = time.perf_counter()
+    f.barrier(1, 1)
+    q.put(time.perf_counter() - t)
+    f.close()
+
+
+def test_a_sleeping_rank_0_is_woken_by_the_late_rank_not_by_a_polling_slice():
+    """rank 0 has long stopped spinning when the last rank arrives 50 ms late: the arriving rank sees rank 0's note and wakes it (futex), so the barrier closes
+    within a scheduling delay of the arrival — for BOTH sides — not after the rest of a sleep slice"""
+    name = _name("d")
+    f0 = lp.HostFrame.create(name, 8, 8, 2, host_only=True)
+    q = mp.get_context("spawn").Queue()
+    p = mp.get_context("spawn").Process(target=_late, args=(name, 2, 0.05, q))
+    p.start()
+    time.sleep(0.0)
+    f0.barrier(0, 1, timeout_ms=20000)      # blocks until the late rank arrives (process start + 50 ms)
+    t_done = time.perf_counter()
+    late_side = q.get(timeout=60)
+    p.join(60)
+    assert late_side < 0.02, late_side       # the late rank leaves the barrier within milliseconds of entering it
+    f0.close()
