@@ -243,6 +243,9 @@ struct lpt_renderer {
     // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
     bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
+    // the same launches' tails finished IN PLACE instead (kernels.h trace_tail): a wave whose queues are dry and that is down to this many live rays finishes them
+    // cooperatively from where they stand; 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
+    uint32_t tail_lanes = 0u;
     uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
     // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
     uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 0u, pool_waves = 8u;   // pool_entries 0: 256 records per wave of a block
@@ -1459,6 +1462,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_POOL_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_REFILL: 0..63"); r->pool_refill = (int)value; break;
     case LPT_OPT_SPLIT_RAYS: r->split_rays = value; break;
     case LPT_OPT_BUDGET_SPLIT: r->budget_split = value != 0; break;
+    case LPT_OPT_TAIL_LANES: r->tail_lanes = (uint32_t)std::min<uint64_t>(value, kTailMax); break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1487,6 +1491,7 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_POOL_REFILL: *value = (uint64_t)r->pool_refill; break;
     case LPT_OPT_SPLIT_RAYS: *value = r->split_rays; break;
     case LPT_OPT_BUDGET_SPLIT: *value = r->budget_split; break;
+    case LPT_OPT_TAIL_LANES: *value = r->tail_lanes; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1727,18 +1732,25 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // pieces of a cut batch overlap on the renderer's lanes and hide each other's tails: 1/2 shard as two wavefronts 6.84 ms without, 6.93 with it
         // (not with the stats kernels: a ray dropped at the budget would be missing from the steps-per-ray histogram and its partial node / triangle counts would be
         // counted again by the cooperative kernel's full re-trace — ADVICE r04)
-        const uint32_t budget = (!r->stats && r->step_budget && (solo || r->budget_split) && n_rays <= r->budget_rays) ? r->step_budget : 0u;
+        const bool tail_launch = !r->stats && (solo || r->budget_split) && n_rays <= r->budget_rays;
+        // ... the tail finished in place (trace_tail) comes first where it is on: nothing is dropped then, so there is nothing to re-trace
+        const uint32_t tail = tail_launch ? std::min(std::min(r->tail_lanes, kTailMax), (uint32_t)std::max(r->refill, 0)) : 0u;
+        const uint32_t budget = (tail_launch && !tail && r->step_budget) ? r->step_budget : 0u;
+        const size_t tail_lds = tail ? sizeof(uint32_t) * tail_lds_words(r->sg->stats.max_depth) : 0u;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
             const int launch_no = cb >= 0 ? cb : (int)nb;   // which strag_count[] this launch fills
-            if (pipe) {
-                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
-                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
-            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no);
+            if (tail) {
+                if (pipe) hipLaunchKernelGGL((k_trace<false, true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
+                else hipLaunchKernelGGL((k_trace<false, false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
+            } else if (pipe) {
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
+                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
             if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
-                const size_t clds = sizeof(uint32_t) * coop_stack_entries(r->sg->stats.max_depth);
+                const size_t clds = sizeof(uint32_t) * coop_stack_entries(kCoopStack, r->sg->stats.max_depth);
                 if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * kCoopWavesPerCu), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
                 else hipLaunchKernelGGL(k_trace_coop<false>, dim3(cus * kCoopWavesPerCu), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
             }

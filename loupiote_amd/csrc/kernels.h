@@ -739,9 +739,222 @@ __device__ __forceinline__ uint32_t occ_key(const OccProbe &oc, f3 o) {
 // of ray it carries.  Results are identical to k_intersect followed by k_shadow: the only shared state is
 // Lsum, which only the shadow part touches.
 // PIPE: ray_step_pipe (one memory round trip per step) instead of ray_step_any — same results, for launches of few rays.
-template <bool STATS, bool PIPE = false>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
-                                                       int cb, int sb, int refill, OccProbe occ, uint32_t budget, uint32_t *strag, int launch) {
+// ---- one ray, a whole wave (k_trace_coop, and the tail of k_trace) ----------------------------------------------------------------------------------
+// Eight lanes per node (lane j of a group tests child j), up to eight pending nodes of the ray per round.  The node stack (node indices) is one LDS
+// column per wave.  A lane tests the triangles of the leaf child it found; a round's candidates are merged by the rule of the per-lane traversal — the
+// smallest t, ties to the lower primitive id — through a 64-bit key, so the hit (t, u, v, prim) is the one the per-lane steps find: the slab tests are
+// conservative on both sides and only the Woop test decides (SPEC §7).
+// A round pops m <= 8 nodes and pushes at most 8 m.  Up to `cap` entries the walk is as broad as it can be; beyond, m = 1: depth first, which adds at
+// most 7 entries per level below the node it pops — the host sizes the LDS column for cap + 8 + 7 * (tree depth + 1) entries (coop_stack_entries), so the
+// column cannot overflow whatever the ray's frontier looks like.
+constexpr uint32_t kCoopStack = 384u;   // k_trace_coop: a straggler's walk starts at the root and may be broad
+constexpr uint32_t kTailStack = 64u;    // k_trace's tail: the walk starts from a lane's depth-first frontier (at most 7 * depth + 1 nodes, below the column's size either way)
+__host__ __device__ __forceinline__ uint32_t coop_stack_entries(uint32_t cap, uint32_t tree_depth) { return cap + 8u + 7u * (tree_depth + 1u); }
+
+// a round's candidates (at most one per lane) into the ray's best hit; every lane ends with the same `best`
+__device__ __forceinline__ void coop_merge(Hit &best, const bool cand, const float ct, const float cu, const float cv, const uint32_t cprim) {
+    // the wave's smallest (t, prim): t > 0, so its bit pattern orders like its value
+    unsigned long long key = cand ? (((unsigned long long)__float_as_uint(ct) << 32) | cprim) : ~0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long other = __shfl_xor(key, off);
+        key = other < key ? other : key;
+    }
+    const unsigned long long old = ((unsigned long long)__float_as_uint(best.t) << 32) | best.prim;
+    if (key < old) {
+        const int src = __ffsll((long long)__ballot(cand && ((((unsigned long long)__float_as_uint(ct) << 32) | cprim) == key))) - 1;
+        best.t = __shfl(ct, src); best.u = __shfl(cu, src); best.v = __shfl(cv, src); best.prim = __shfl(cprim, src);
+    }
+}
+
+// the rounds: `count` node indices wait in stk[0..count); all arguments but the lane's own role are wave-uniform.  Shadow rays: best.prim = 0 as soon as anything is hit
+template <bool STATS>
+__device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3 d, const float ix, const float iy, const float iz, const bool shadow, Hit &best,
+                                          uint32_t *stk, uint32_t count, const uint32_t cap, const uint32_t lane, uint32_t &n_nodes, uint32_t &n_tris) {
+    const uint32_t grp = lane >> 3, c = lane & 7u;
+    const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+    bool done = false;
+    while (count && !done) {
+        const uint32_t room = count < cap ? cap - count : 0u;
+        const uint32_t m = min(min(count, 8u), max(room / 7u, 1u));
+        const bool work = grp < m;
+        uint32_t node = 0u;
+        if (work) node = stk[count - 1u - grp];
+        __syncthreads();            // every pop is read before the pushes below overwrite the slots
+        count -= m;
+        bool hit_inner = false, hit_leaf = false;
+        uint32_t child = 0u, first = 0u, bits = 0u;
+        if (work) {
+            const DNode8 *n = sc.nodes + node;
+            const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
+            const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
+            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
+            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
+            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
+            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
+            const float by = (__uint_as_float(n0.y) - o.y) * iy;
+            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+            const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
+            const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
+            const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
+            const uint32_t sh = 8u * (c & 3u);
+            const bool hi4 = c >= 4u;
+            const uint32_t lox = ((hi4 ? n2.y : n2.x) >> sh) & 0xFFu, loy = ((hi4 ? n2.w : n2.z) >> sh) & 0xFFu, loz = ((hi4 ? n3.y : n3.x) >> sh) & 0xFFu;
+            const uint32_t hix = ((hi4 ? n3.w : n3.z) >> sh) & 0xFFu, hiy = ((hi4 ? n4.y : n4.x) >> sh) & 0xFFu, hiz = ((hi4 ? n4.w : n4.z) >> sh) & 0xFFu;
+            const float tnx = fmaf((float)(negx ? hix : lox), ax, bx - ex), tfx = fmaf((float)(negx ? lox : hix), ax, bx + ex);
+            const float tny = fmaf((float)(negy ? hiy : loy), ay, by - ey), tfy = fmaf((float)(negy ? loy : hiy), ay, by + ey);
+            const float tnz = fmaf((float)(negz ? hiz : loz), az, bz - ez), tfz = fmaf((float)(negz ? loz : hiz), az, bz + ez);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+            const uint32_t imask = n0.w >> 24;
+            const uint32_t meta = ((hi4 ? n1.w : n1.z) >> sh) & 0xFFu;
+            const bool inner = ((imask >> c) & 1u) != 0u;
+            const bool hit = tn <= tf && meta != 0u;     // empty slots: meta 0 (their boxes are inverted as well)
+            hit_inner = hit && inner;
+            hit_leaf = hit && !inner;
+            child = n1.x + (uint32_t)__popc(imask & ~(0xFFFFFFFFu << c));
+            first = n1.y + (meta & 31u);
+            bits = meta >> 5;
+        }
+        if (STATS) n_nodes += m;
+        // inner children: appended to the stack (ballot + prefix count)
+        const unsigned long long im = __ballot(hit_inner);
+        if (hit_inner) stk[count + (uint32_t)__popcll(im & ((1ull << lane) - 1ull))] = child;
+        count += (uint32_t)__popcll(im);
+        // leaf children: the lane tests its (up to three) triangles against the round's best
+        float ct = 0.f, cu = 0.f, cv = 0.f;
+        uint32_t cprim = 0xFFFFFFFFu;
+        bool cand = false;
+        if (hit_leaf) {
+            for (uint32_t k = 0; k < 3u; ++k) {
+                if (!((bits >> k) & 1u)) continue;
+                const uint32_t ti = first + k;
+                const float4 *w = sc.woop + 3u * (size_t)ti;
+                const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+                float t, u, v;
+                if (ray_triangle(r0, r1, r2, o, d, cand ? ct : best.t, t, u, v)) {
+                    const uint32_t prim = sc.leaf_prim[ti];
+                    if (!cand || t < ct || prim < cprim) { ct = t; cu = u; cv = v; cprim = prim; cand = true; }
+                }
+            }
+        }
+        if (STATS) n_tris += (uint32_t)__popcll(__ballot(hit_leaf));
+        if (__ballot(cand)) {
+            if (shadow) { best.prim = 0u; done = true; }   // any hit in (0, tmax] occludes
+            else coop_merge(best, cand, ct, cu, cv, cprim);
+        }
+        __syncthreads();            // the pushes are visible to the next round's pops
+    }
+}
+
+// THE TAIL OF A TRAVERSAL LAUNCH, IN PLACE.  A launch lasts as long as its last ray, and a lane takes one dependent step (~1.3 us) per node.
+// A wave whose queues are dry and that is down to `tail` live rays or fewer stops stepping them lane by lane and finishes them one after the other with all 64
+// lanes, each from where its lane stands: the ray's frontier — the node groups on the lane's LDS stack and the one in hand, expanded to node indices — seeds the
+// cooperative walk above, the triangle groups the lane still holds are tested first, the best hit so far carries over.  Nothing is restarted at the root and
+// no second launch is needed (the step budget + k_trace_coop pair this replaces: 48 steps thrown away per straggler, ~15 us of launch per bounce).
+// `columns` = the wave's per-lane stacks (entry e of lane L at columns[e * kTraceBlock + L]); `tail_lds` = tail_lds_words(depth) words behind them: the live
+// rays' states first (parked there so that the per-lane state's registers are free during the walks: the kernel keeps its 78 VGPRs), then the node column.
+constexpr uint32_t kTailMax = 8u;          // rays a wave finishes this way at most (one after the other: beyond a handful the per-lane steps are faster)
+constexpr uint32_t kTailStateWords = 20u;  // five 16-byte rows per ray
+__host__ __device__ __forceinline__ uint32_t tail_lds_words(uint32_t tree_depth) { return kTailMax * kTailStateWords + coop_stack_entries(kTailStack, tree_depth); }
+// the lane's part, inside the traversal loop: park the live rays' states; returns their number
+template <bool PIPE>
+__device__ __forceinline__ uint32_t tail_park(const RayState &rs, const unsigned long long live, const bool lane_active, const bool lane_shadow, const uint32_t lane_ray, uint32_t *tail_lds) {
+    uint32_t lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));   // opaque: what is derived from it is computed HERE, not hoisted in front of the traversal loop (where it would cost the loop registers)
+    if (lane_active) {
+        uint4 *st = reinterpret_cast<uint4 *>(tail_lds) + 5u * (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
+        st[0] = make_uint4(__float_as_uint(rs.o.x), __float_as_uint(rs.o.y), __float_as_uint(rs.o.z), __float_as_uint(rs.d.x));
+        st[1] = make_uint4(__float_as_uint(rs.d.y), __float_as_uint(rs.d.z), __float_as_uint(rs.best.t), __float_as_uint(rs.best.u));
+        st[2] = make_uint4(__float_as_uint(rs.best.v), rs.best.prim, rs.ng.x, rs.ng.y);
+        st[3] = make_uint4(rs.tg.x, rs.tg.y, PIPE ? rs.tg2.x : 0u, PIPE ? rs.tg2.y : 0u);
+        st[4] = make_uint4((uint32_t)rs.sp | (lane_shadow ? 0x80000000u : 0u), lane_ray, lane, 0u);
+    }
+    return (uint32_t)__popcll(live);
+}
+// the wave's part: a function of its own (not inlined), so that its registers are allocated apart from the traversal loop's — inlined, the loop above it spills
+struct TailArgs { const DNode8 *nodes; const float4 *woop; const uint32_t *leaf_prim; const lpt_light *lights; uint32_t n_lights, stack_entries, n_live; float4 *hits; const float4 *sq_c; float4 *Lsum; };
+__device__ __forceinline__ void tail_walk(const TailArgs a) {
+    static_assert(kTraceBlock == 64, "one wave per block: the cooperative stack is the wave's");
+    DScene sc = {};
+    sc.nodes = a.nodes; sc.woop = a.woop; sc.leaf_prim = a.leaf_prim; sc.lights = a.lights; sc.n_lights = a.n_lights;
+    uint32_t lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));   // as in tail_park
+    const uint2 *columns = reinterpret_cast<const uint2 *>(lds_dyn);
+    uint32_t *tail_lds = reinterpret_cast<uint32_t *>(lds_dyn + a.stack_entries * kTraceBlock * sizeof(uint2));
+    const uint4 *state = reinterpret_cast<const uint4 *>(tail_lds);
+    uint32_t *stk = tail_lds + kTailMax * kTailStateWords;
+    __syncthreads();
+    for (uint32_t r = 0; r < a.n_live; ++r) {
+        const uint4 s0 = state[5u * r], s1 = state[5u * r + 1u], s2 = state[5u * r + 2u], s3 = state[5u * r + 3u], s4 = state[5u * r + 4u];
+        const f3 o = mk3(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z)), d = mk3(__uint_as_float(s0.w), __uint_as_float(s1.x), __uint_as_float(s1.y));
+        const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);          // as ray_begin
+        const uint32_t oinv = 7u - ((ix < 0.0f ? 1u : 0u) | (iy < 0.0f ? 2u : 0u) | (iz < 0.0f ? 4u : 0u));
+        Hit best;
+        best.t = __uint_as_float(s1.z); best.u = __uint_as_float(s1.w); best.v = __uint_as_float(s2.x); best.prim = s2.y;
+        const uint32_t slot_bits = s1.w;   // a shadow ray's pixel slot rides in `u` (k_trace)
+        const uint2 ng = make_uint2(s2.z, s2.w);
+        const bool shadow = (s4.x >> 31) != 0u;
+        const int sp = (int)(s4.x & 0x7FFFFFFFu);
+        const uint32_t ray = s4.y, L = s4.z;
+        // the frontier: groups 0..sp-1 of the lane's column, then the group in hand (the deepest on top, and within a group the bit the lane would take next)
+        uint32_t count = 0u;
+        for (int base = 0; base <= sp; base += 8) {
+            const int e = base + (int)(lane >> 3);
+            uint2 g = make_uint2(0u, 0u);
+            if (e < sp) g = columns[e * kTraceBlock + L];
+            else if (e == sp) g = ng;
+            const uint32_t bit = lane & 7u;
+            const bool has = ((g.y >> (24u + bit)) & 1u) != 0u;
+            const uint32_t slot = bit ^ oinv;
+            const uint32_t node = g.x + (uint32_t)__popc(g.y & ~(0xFFFFFFFFu << slot));   // node_visit's `rel`: the inner children before the slot
+            const unsigned long long hm = __ballot(has);
+            if (has) stk[count + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = node;
+            count += (uint32_t)__popcll(hm);
+        }
+        // the triangles the lane had found and not yet tested: lanes 0..23 the group in work, 24..47 the one waiting behind it (one-round-trip step)
+        bool done = false;
+        {
+            const uint32_t k = lane < 24u ? lane : lane - 24u;
+            const uint2 g = lane < 24u ? make_uint2(s3.x, s3.y) : make_uint2(s3.z, s3.w);
+            const bool mine = lane < 48u && ((g.y >> k) & 1u) != 0u;
+            float ct = 0.f, cu = 0.f, cv = 0.f;
+            uint32_t cprim = 0xFFFFFFFFu;
+            bool cand = false;
+            if (mine) {
+                const uint32_t ti = g.x + k;
+                const float4 *w = sc.woop + 3u * (size_t)ti;
+                const float4 r0 = w[0], r1 = w[1], r2 = w[2];
+                if (ray_triangle(r0, r1, r2, o, d, best.t, ct, cu, cv)) { cprim = sc.leaf_prim[ti]; cand = true; }
+            }
+            if (__ballot(cand)) {
+                if (shadow) { best.prim = 0u; done = true; }
+                else coop_merge(best, cand, ct, cu, cv, cprim);
+            }
+        }
+        __syncthreads();            // the frontier is in the column before the first round pops it
+        uint32_t nn = 0, nt = 0;
+        if (!done) coop_walk<false>(sc, o, d, ix, iy, iz, shadow, best, stk, count, kTailStack, lane, nn, nt);
+        if (shadow) {
+            if (lane == 0 && best.prim == 0xFFFFFFFFu) {   // unoccluded: deposit the light sample
+                const float4 cc = a.sq_c[ray];
+                float4 Lp = a.Lsum[slot_bits];
+                Lp.x = Lp.x + cc.x; Lp.y = Lp.y + cc.y; Lp.z = Lp.z + cc.z;
+                a.Lsum[slot_bits] = Lp;
+            }
+        } else {
+            intersect_lights(sc, o, d, best);
+            if (lane == 0) st_nt(a.hits + ray, make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)));
+        }
+        __syncthreads();            // the column is reused by the next ray
+    }
+}
+
+// TAIL: the variant whose waves finish their last rays cooperatively (tail_walk); kept to the 6 waves per SIMD of the one-round-trip step (without the attribute the
+// compiler takes the extra code as a licence for 90-100 VGPRs in the loop).  The other variants are compiled as before.
+template <bool STATS, bool PIPE = false, bool TAIL = false>
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAIL ? 6 : 1))) void k_trace(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
+                                                       int cb, int sb, int refill, OccProbe occ, uint32_t budget, uint32_t *strag, int launch, uint32_t tail) {
     uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
     ChunkPuller pc, ps;
     puller_init(pc, &ctr->ihead[(cb < 0 ? 0 : cb) * 8 * 32], cb < 0 ? 0u : QC(ctr, cb));
@@ -816,6 +1029,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
                 const uint32_t adv = min(en, nx + (uint32_t)(64 - n_active));
                 if (use_s) ps.next = adv; else pc.next = adv;
             } else if (n_active == 0) break;
+            else if (TAIL && n_active <= (int)tail) {
+                // both queues are dry and few rays are left: the wave finishes them cooperatively, in place (trace_tail; the host sets `tail` only without the stats)
+                TailArgs ta = {sc.nodes, sc.woop, sc.leaf_prim, sc.lights, sc.n_lights, sc.stack_entries, 0u, hits, sq.c, Lsum};
+                ta.n_live = tail_park<PIPE>(rs, amask, active, shadow, ray, reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2)));
+                tail_walk(ta);
+                break;
+            }
         }
         uint32_t dn = 0, dt = 0;
         if (STATS) {
@@ -863,22 +1083,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, Queue q, float
     }
 }
 
-// The stragglers of a traversal launch, each traced by a WHOLE WAVE: eight lanes per node (lane j of a group tests child j), up to eight pending
-// nodes of the ray per round, so a ray that would take a lane 100-360 dependent steps takes the wave 15-40 rounds.  The node stack (node indices)
-// is one LDS column per wave.  A lane tests the triangles of the leaf child it found; a round's candidates are merged by the rule of the per-lane
-// traversal — the smallest t, ties to the lower primitive id — through a 64-bit key, so the hit (t, u, v, prim) is the one k_trace finds: the slab
-// tests are conservative on both sides and only the Woop test decides (SPEC §7).  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
-// Node indices.  A round pops m <= 8 nodes and pushes at most 8 m.  Up to kCoopStack entries the walk is as broad as it can be; beyond, m = 1: depth first,
-// which adds at most 7 entries per level below the node it pops — the host sizes the LDS column for kCoopStack + 8 + 7 * (tree depth + 1) entries
-// (coop_stack_bytes), so the column cannot overflow whatever the ray's frontier looks like.
-constexpr uint32_t kCoopStack = 384u;
-__host__ __device__ __forceinline__ uint32_t coop_stack_entries(uint32_t tree_depth) { return kCoopStack + 8u + 7u * (tree_depth + 1u); }
+// The stragglers of a traversal launch (k_trace with a step budget), each traced again from the root by a WHOLE WAVE (coop_walk above): a ray that would
+// take a lane 100-360 dependent steps takes the wave 15-40 rounds.  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
                                                             int cb, int sb, const uint32_t *strag, int launch) {
     static_assert(kTraceBlock == 64, "one wave per block: the LDS stack is the wave's");
-    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // coop_stack_entries(depth) node indices (host)
-    const uint32_t lane = threadIdx.x, grp = lane >> 3, c = lane & 7u;
+    uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // coop_stack_entries(kCoopStack, depth) node indices (host)
+    const uint32_t lane = threadIdx.x;
     const uint32_t n_strag = ctr->strag_count[launch];
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
     for (uint32_t si = blockIdx.x; si < n_strag; si += gridDim.x) {
@@ -887,99 +1099,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, 
         const uint32_t ray = e & 0x7FFFFFFFu;
         const float4 o4 = shadow ? sq.o[ray] : q.o[ray], d4 = shadow ? sq.d[ray] : q.d[ray];
         const f3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-        const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
-        const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
         Hit best;
         best.t = shadow ? o4.w : LPT_T_INF; best.u = 0.f; best.v = 0.f; best.prim = 0xFFFFFFFFu;
-        uint32_t count = 1u;            // wave-uniform
         if (lane == 0) stk[0] = 0u;     // the root
         __syncthreads();
-        bool done = false;
-        while (count && !done) {
-            const uint32_t room = count < kCoopStack ? kCoopStack - count : 0u;
-            const uint32_t m = min(min(count, 8u), max(room / 7u, 1u));
-            const bool work = grp < m;
-            uint32_t node = 0u;
-            if (work) node = stk[count - 1u - grp];
-            __syncthreads();            // every pop is read before the pushes below overwrite the slots
-            count -= m;
-            bool hit_inner = false, hit_leaf = false;
-            uint32_t child = 0u, first = 0u, bits = 0u;
-            if (work) {
-                const DNode8 *n = sc.nodes + node;
-                const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
-                const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
-                const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
-                const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
-                const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
-                const float bx = (__uint_as_float(n0.x) - o.x) * ix;
-                const float by = (__uint_as_float(n0.y) - o.y) * iy;
-                const float bz = (__uint_as_float(n0.z) - o.z) * iz;
-                const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
-                const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
-                const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
-                const uint32_t sh = 8u * (c & 3u);
-                const bool hi4 = c >= 4u;
-                const uint32_t lox = ((hi4 ? n2.y : n2.x) >> sh) & 0xFFu, loy = ((hi4 ? n2.w : n2.z) >> sh) & 0xFFu, loz = ((hi4 ? n3.y : n3.x) >> sh) & 0xFFu;
-                const uint32_t hix = ((hi4 ? n3.w : n3.z) >> sh) & 0xFFu, hiy = ((hi4 ? n4.y : n4.x) >> sh) & 0xFFu, hiz = ((hi4 ? n4.w : n4.z) >> sh) & 0xFFu;
-                const float tnx = fmaf((float)(negx ? hix : lox), ax, bx - ex), tfx = fmaf((float)(negx ? lox : hix), ax, bx + ex);
-                const float tny = fmaf((float)(negy ? hiy : loy), ay, by - ey), tfy = fmaf((float)(negy ? loy : hiy), ay, by + ey);
-                const float tnz = fmaf((float)(negz ? hiz : loz), az, bz - ez), tfz = fmaf((float)(negz ? loz : hiz), az, bz + ez);
-                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-                const uint32_t imask = n0.w >> 24;
-                const uint32_t meta = ((hi4 ? n1.w : n1.z) >> sh) & 0xFFu;
-                const bool inner = ((imask >> c) & 1u) != 0u;
-                const bool hit = tn <= tf && meta != 0u;     // empty slots: meta 0 (their boxes are inverted as well)
-                hit_inner = hit && inner;
-                hit_leaf = hit && !inner;
-                child = n1.x + (uint32_t)__popc(imask & ~(0xFFFFFFFFu << c));
-                first = n1.y + (meta & 31u);
-                bits = meta >> 5;
-            }
-            if (STATS) { if (shadow) s_nodes += m; else n_nodes += m; }
-            // inner children: appended to the stack (ballot + prefix count)
-            const unsigned long long im = __ballot(hit_inner);
-            if (hit_inner) stk[count + (uint32_t)__popcll(im & ((1ull << lane) - 1ull))] = child;
-            count += (uint32_t)__popcll(im);
-            // leaf children: the lane tests its (up to three) triangles against the round's best
-            float ct = 0.f, cu = 0.f, cv = 0.f;
-            uint32_t cprim = 0xFFFFFFFFu;
-            bool cand = false;
-            if (hit_leaf) {
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    if (!((bits >> k) & 1u)) continue;
-                    const uint32_t ti = first + k;
-                    const float4 *w = sc.woop + 3u * (size_t)ti;
-                    const float4 r0 = w[0], r1 = w[1], r2 = w[2];
-                    float t, u, v;
-                    if (ray_triangle(r0, r1, r2, o, d, cand ? ct : best.t, t, u, v)) {
-                        const uint32_t prim = sc.leaf_prim[ti];
-                        if (!cand || t < ct || prim < cprim) { ct = t; cu = u; cv = v; cprim = prim; cand = true; }
-                    }
-                }
-            }
-            if (STATS) { const uint32_t nt = (uint32_t)__popcll(__ballot(hit_leaf)); if (shadow) s_tris += nt; else n_tris += nt; }
-            const unsigned long long cm = __ballot(cand);
-            if (cm) {
-                if (shadow) { best.prim = 0u; done = true; }   // any hit in (0, tmax] occludes
-                else {
-                    // the wave's smallest (t, prim): t > 0, so its bit pattern orders like its value
-                    unsigned long long key = cand ? (((unsigned long long)__float_as_uint(ct) << 32) | cprim) : ~0ull;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const unsigned long long other = __shfl_xor(key, off);
-                        key = other < key ? other : key;
-                    }
-                    const unsigned long long old = ((unsigned long long)__float_as_uint(best.t) << 32) | best.prim;
-                    if (key < old) {
-                        const int src = __ffsll((long long)__ballot(cand && ((((unsigned long long)__float_as_uint(ct) << 32) | cprim) == key))) - 1;
-                        best.t = __shfl(ct, src); best.u = __shfl(cu, src); best.v = __shfl(cv, src); best.prim = __shfl(cprim, src);
-                    }
-                }
-            }
-            __syncthreads();            // the pushes are visible to the next round's pops
-        }
+        if (shadow) coop_walk<STATS>(sc, o, d, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z), true, best, stk, 1u, kCoopStack, lane, s_nodes, s_tris);
+        else coop_walk<STATS>(sc, o, d, safe_inv(d.x), safe_inv(d.y), safe_inv(d.z), false, best, stk, 1u, kCoopStack, lane, n_nodes, n_tris);
         if (shadow) {
             if (lane == 0 && best.prim == 0xFFFFFFFFu) {   // unoccluded: deposit the light sample
                 const uint32_t slot = __float_as_uint(d4.w);
