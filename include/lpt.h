@@ -583,7 +583,8 @@ typedef enum lpt_option {
     LPT_OPT_BUDGET_SPLIT = 21,      /* 1: the step budget also applies to the pieces of a cut batch (default 0: only to submissions that leave as one wavefront) */
     LPT_OPT_TAIL_LANES = 22         /* the same launches' tails finished IN PLACE: a wave of the per-lane kernel whose queues are dry and that is down to this
                                      * many live rays (1..8) finishes them cooperatively, all 64 lanes per ray, from where each stands — nothing is
-                                     * dropped, restarted at the root or launched behind (replaces LPT_OPT_STEP_BUDGET where it is on); 0 = off */
+                                     * dropped, restarted at the root or launched behind.  Default 4; 0 = off, and LPT_OPT_STEP_BUDGET applies instead.  Like the budget, not used while
+                                     * lpt_renderer_enable_stats is on */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

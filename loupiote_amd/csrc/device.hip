@@ -244,8 +244,8 @@ struct lpt_renderer {
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
     bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
     // the same launches' tails finished IN PLACE instead (kernels.h trace_tail): a wave whose queues are dry and that is down to this many live rays finishes them
-    // cooperatively from where they stand; 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
-    uint32_t tail_lanes = 0u;
+    // cooperatively from where they stand (default); 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
+    uint32_t tail_lanes = 4u;      // 1/8 shard of the bench frame: 3, 4, 5 the same (2.74 ms per frame against 2.90 with the budget pair), 2 and 8 slower
     uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
     // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
     uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 0u, pool_waves = 8u;   // pool_entries 0: 256 records per wave of a block

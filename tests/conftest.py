@@ -45,8 +45,10 @@ PIPELINES = {
     # kernel at every resolution (the default picks it by pixel footprint: not for the small frames most tests render)
     "path": {"path_rays": 0x7FFFFFFF, "packet_primary": 1},
     # the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace) with a step budget of 16 (default 48), so that in every parity test a good part of the
-    # rays is finished by the wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; the packet choice is the library's
-    "per_bounce": {"path_rays": 0, "step_budget": 16},
+    # rays is finished by the wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; the packet choice is the library's.  tail_lanes 0: the
+    # shipped form of these launches — tails finished in place instead of a budget — runs in the "default" arm (where the frame takes the per-bounce launches) and
+    # in tests/test_gpu_tail.py
+    "per_bounce": {"path_rays": 0, "step_budget": 16, "tail_lanes": 0},
     # round 5: the CU-local pool of trace and shade work (k_pool): records handed between the waves of a block through LDS rings, hits shaded by kind
     "pool": {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "packet_primary": 1},
     # the configuration as shipped: nothing forced (kernel choice by ray count and pixel footprint, default budget, quad packets) — ADVICE r04

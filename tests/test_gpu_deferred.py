@@ -270,8 +270,11 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
                 {"path_waves_per_cu": 3, "path_refill": 20, "packet_primary": 1}, {"path_refill": 63}, {"path_refill": 0},
                 # the step budget: rays not finished after n steps are dropped by the per-lane kernel and traced again by a whole wave (k_trace_coop);
                 # n = 1: every ray of the per-bounce launches goes that way
-                {"path_rays": 0, "step_budget": 0}, {"path_rays": 0, "step_budget": 1}, {"path_rays": 0, "step_budget": 7, "packet_primary": 1}, {"path_rays": 0, "step_budget": 12, "pipe_rays": 0},
-                {"path_rays": 0, "step_budget": 3, "budget_rays": 10})
+                {"path_rays": 0, "step_budget": 0, "tail_lanes": 0}, {"path_rays": 0, "step_budget": 1, "tail_lanes": 0}, {"path_rays": 0, "step_budget": 7, "packet_primary": 1, "tail_lanes": 0},
+                {"path_rays": 0, "step_budget": 12, "pipe_rays": 0, "tail_lanes": 0},
+                {"path_rays": 0, "step_budget": 3, "budget_rays": 10, "tail_lanes": 0},
+                # the shipped form of the same launches: tails finished in place (tests/test_gpu_tail.py)
+                {"path_rays": 0, "tail_lanes": 4}, {"path_rays": 0, "tail_lanes": 8, "pipe_rays": 0})
     for opts in variants:
         r = _renderer(device, sg, pr, 0, options=opts)
         assert all(r.get_option(k) == v for k, v in opts.items())

@@ -165,7 +165,7 @@ for stats in (0, 1):
     r.close()
 print(json.dumps(sums))
 ''' % root
-    for opts in ({"pipe_rays": 0}, {"pipe_rays": 0, "merge_trace": 0}, {}, {"path_rays": 0x7FFFFFFF}, {"path_rays": 0, "pool_rays": 0x7FFFFFFF}, {"pipe_rays": 0, "step_budget": 8, "budget_rays": 0x7FFFFFFF}):
+    for opts in ({"pipe_rays": 0}, {"pipe_rays": 0, "merge_trace": 0}, {}, {"path_rays": 0x7FFFFFFF}, {"path_rays": 0, "pool_rays": 0x7FFFFFFF}, {"pipe_rays": 0, "step_budget": 8, "budget_rays": 0x7FFFFFFF, "tail_lanes": 0}, {"path_rays": 0, "tail_lanes": 8, "budget_rays": 0x7FFFFFFF}):
         p = subprocess.run([sys.executable, "-c", code, json.dumps(opts)], capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (opts, p.stderr[-1500:])
         plain, stats = json.loads(p.stdout.strip().splitlines()[-1])
