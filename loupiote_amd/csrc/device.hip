@@ -2053,6 +2053,17 @@ int lpt_renderer_synchronize(lpt_renderer *r) {
     return check_device_error(r);
 }
 
+#ifdef LPT_EXP_WAVETIMES
+// A/B builds only (kernels.h LPT_EXP_WAVETIMES): the per-wave timing records the traversal launches of lane `lane`'s last wavefront left in its straggler list
+int lpt_debug_read_wave_times(lpt_renderer *r, uint32_t lane, uint32_t *dst, uint32_t words) {
+    if (!r || lane >= (uint32_t)kMaxLanes || !r->wf[lane].strag || (size_t)words > 2u * r->wf[lane].ray_cap) return fail(LPT_ERR_INVALID_ARG, "lpt_debug_read_wave_times");
+    FLUSH_OR_RETURN(r);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(dst, r->wf[lane].strag, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
+    return LPT_OK;
+}
+#endif
+
 int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes) {
     if (!r || !ptr) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_radiance_device_ptr: null");
     FLUSH_OR_RETURN(r);

@@ -971,6 +971,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
+#ifdef LPT_EXP_WAVETIMES
+    // timing probe (A/B builds only, `make variant`; tools/dev/r05_wave_times.py): when did this wave start, find its queues dry, enter the tail, end — in
+    // 10 ns ticks of the constant clock, dumped into the (otherwise unused) straggler list: 8 words per wave and launch
+    const uint32_t wt_start = (uint32_t)wall_clock64();
+    uint32_t wt_dry = 0u, wt_tail = 0u, wt_ndry = 0u, wt_ntail = 0u, wt_steps = 0u;
+#endif
     for (;;) {
         const unsigned long long amask = __ballot(active);
         const int n_active = __popcll(amask);
@@ -1014,6 +1020,10 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             const bool use_s = !(pc.next < pc.end);  // wave-uniform
             if (use_s) puller_pull(ps);
             const uint32_t nx = use_s ? ps.next : pc.next, en = use_s ? ps.end : pc.end;
+#ifdef LPT_EXP_WAVETIMES
+            if (!(nx < en) && !wt_dry) { wt_dry = (uint32_t)wall_clock64() | 1u; wt_ndry = (uint32_t)n_active; }
+            if (!(nx < en) && TAIL && n_active && n_active <= (int)tail) { wt_tail = (uint32_t)wall_clock64() | 1u; wt_ntail = (uint32_t)n_active; }
+#endif
             if (nx < en) {
                 const uint32_t idx = nx + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
                 if (!active && idx < en) {
@@ -1037,6 +1047,9 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
                 break;
             }
         }
+#ifdef LPT_EXP_WAVETIMES
+        if (wt_dry) wt_steps++;
+#endif
         uint32_t dn = 0, dt = 0;
         if (STATS) {
             w_steps++;
@@ -1061,6 +1074,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             if (shadow) { s_nodes += dn; s_tris += dt; } else { n_nodes += dn; n_tris += dt; }
         }
     }
+#ifdef LPT_EXP_WAVETIMES
+    if (lane == 0 && strag) {
+        uint32_t *o = strag + ((uint32_t)launch * 8192u + blockIdx.x) * 8u;
+        o[0] = wt_start; o[1] = wt_dry; o[2] = wt_tail; o[3] = (uint32_t)wall_clock64(); o[4] = wt_ndry; o[5] = wt_ntail; o[6] = wt_steps; o[7] = 0x57415645u;
+    }
+#endif
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
         atomicAdd(&ctr->tris, (unsigned long long)n_tris);
