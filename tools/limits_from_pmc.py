@@ -42,8 +42,8 @@ GATHER_TBS = (9.7, 13.5)
 
 
 def short(name):
-    # k_trace<STATS, PIPE>: the first template argument (the STATS variant is a different kernel for the averages), not the second
-    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))?>)?", name)
+    # k_trace<STATS, PIPE, TAIL>: the first template argument (the STATS variant is a different kernel for the averages), not the second
+    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))*>)?", name)
     return (m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")) if m else name[:40]
 
 

@@ -7,8 +7,8 @@ from collections import defaultdict
 
 
 def short(name):
-    # k_trace<STATS, PIPE>: keyed by the first template argument (the STATS variant is a different kernel for the averages)
-    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))?>)?", name)
+    # k_trace<STATS, PIPE, TAIL>: keyed by the first template argument (the STATS variant is a different kernel for the averages)
+    m = re.search(r"lptd::(k_[a-z_]+)(<(true|false)(, (true|false))*>)?", name)
     if m:
         return m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")
     return name[:40]
