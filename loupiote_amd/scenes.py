@@ -336,6 +336,52 @@ def synthetic_helmet(seed=1, textures=True, texture_size=2048):
             "camera": {"origin": (0.0, 0.6, 4.2), "direction": (0.0, -0.12, -1.0)}}
 
 
+def synthetic_hall(seed=3, gravel=12000, needles=160, stack=40, telescope=90):
+    """A MIXED-SCALE scene (VERDICT r04 "missing" 7: the stand-ins have uniformly small triangles): a hall of six walls of TWO triangles each (16 units across),
+    a pile of `gravel` triangles 2-3 cm across in one corner, `needles` slivers 6-14 units long and a centimetre wide through the whole volume, the same quad
+    `stack` times in the same place (coincident triangles: equal hit distances, the tie goes to the lowest primitive id; and a subtree no split can separate),
+    and a "telescope" of `telescope` triangles sharing a corner at scales 0.93^k (a tree the builder can only peel one triangle at a time: depth).  Untextured
+    materials, one emitter, the sky probe through an open roof panel."""
+    rng = np.random.default_rng(seed)
+    def soup(tris):   # (n, 3, 3) -> mesh with unshared vertices
+        pos = np.asarray(tris, np.float32).reshape(-1, 3)
+        return _mesh(pos, np.arange(pos.shape[0], dtype=np.uint32))
+    def quad(o, eu, ev):
+        o, eu, ev = (np.asarray(x, np.float32) for x in (o, eu, ev))
+        return [[o, o + eu, o + eu + ev], [o, o + eu + ev, o + ev]]
+    H = 8.0
+    walls = (quad((-H, 0, -H), (0, 0, 2 * H), (2 * H, 0, 0)) + quad((-H, 0, -H), (2 * H, 0, 0), (0, 9, 0)) + quad((H, 0, H), (-2 * H, 0, 0), (0, 9, 0))
+             + quad((-H, 0, H), (0, 0, -2 * H), (0, 9, 0)) + quad((H, 0, -H), (0, 0, 2 * H), (0, 9, 0)) + quad((-H, 9, -H), (2 * H, 0, 0), (0, 0, 1.2 * H)))   # the roof leaves a strip open
+    c = rng.uniform((-7.5, 0.0, -7.5), (-4.5, 1.6, -4.5), (gravel, 1, 3)).astype(np.float32)
+    c[:, 0, 1] *= rng.uniform(0, 1, gravel).astype(np.float32)   # a pile: denser near the floor
+    grav = c + rng.normal(0, 0.012, (gravel, 3, 3)).astype(np.float32)
+    a0 = rng.uniform((-H, 0.2, -H), (H, 8.5, H), (needles, 3)).astype(np.float32)
+    dirn = rng.normal(size=(needles, 3)).astype(np.float32)
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    side = np.cross(dirn, rng.normal(size=(needles, 3))).astype(np.float32)
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    length = rng.uniform(6, 14, (needles, 1)).astype(np.float32)
+    ndl = np.stack([a0, a0 + dirn * length, a0 + dirn * length * 0.5 + side * 0.01], axis=1)
+    one = np.asarray(quad((1.0, 0.8, -2.0), (2.5, 0, 0.4), (0, 2.0, 0.3)), np.float32)
+    stk = np.concatenate([one] * stack + [one[:1] * np.float32(1.0)] * stack, axis=0)         # 3 x stack coincident triangles
+    corner = np.asarray((5.5, 0.05, 5.5), np.float32)
+    tele = np.stack([np.stack([corner, corner + np.float32(0.93 ** k) * np.asarray((-4.0, 0.3, 0.2), np.float32),
+                               corner + np.float32(0.93 ** k) * np.asarray((0.2, 3.5 + 0.01 * k, -4.0), np.float32)]) for k in range(telescope)])
+    meshes = [soup(walls), soup(grav), soup(ndl), soup(stk), soup(tele)]
+    materials = [((0.72, 0.7, 0.66, 1), 0.9, 0.0, INVALID, INVALID), ((0.5, 0.42, 0.3, 1), 0.7, 0.0, INVALID, INVALID), ((0.9, 0.9, 0.92, 1), 0.15, 1.0, INVALID, INVALID),
+                 ((0.8, 0.25, 0.2, 1), 0.4, 0.0, INVALID, INVALID), ((0.3, 0.5, 0.8, 1), 0.25, 0.0, INVALID, INVALID)]
+    ident = _translate(0, 0, 0)
+    instances = [(k + 1, ident, k + 1) for k in range(5)]
+    light = np.zeros(1, dtype=[("normal", "<f4", 4), ("tangent", "<f4", 4), ("bitangent", "<f4", 4), ("origin", "<f4", 4)])
+    light["normal"] = (0, -1, 0, 0)
+    light["tangent"] = (1, 0, 0, 1.5)
+    light["bitangent"] = (0, 0, 1, 1.5)
+    light["origin"] = (0.0, 8.6, -1.0, 30.0)
+    total = sum(m["indices"].size // 3 for m in meshes)
+    return {"name": "synthetic_hall(seed=%d)" % seed, "meshes": meshes, "instances": instances, "materials": materials, "images": [], "lights": [light],
+            "probe": sky_probe(256, 128), "triangles": total, "camera": {"origin": (6.5, 2.2, -6.5), "direction": (-0.75, -0.12, 0.7)}}
+
+
 def to_product(desc):
     """feed a description through the C ABI; returns loupiote_amd.Scene"""
     from . import api

@@ -105,3 +105,17 @@ def test_reinsertion_optimiser_does_not_cost_visits(bvh_check, tmp_path):
     on = run(bvh_check, tmp_path, soup, 20000)
     assert off["mismatches"] == on["mismatches"] == 0 and off["hits"] == on["hits"]
     assert on["nodes_per_ray"] <= 1.01 * off["nodes_per_ray"]
+
+
+def test_mixed_scale_hall_matches_brute_force(bvh_check, tmp_path):
+    """scenes.synthetic_hall: walls of two triangles each around 12 000 centimetre-sized ones, slivers through the whole volume, 120 coincident triangles and a
+    telescope of nested ones — the closest hit (t and lowest primitive id among equals) is the brute-force one from inside the hall, for both collapse modes"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from loupiote_amd import scenes
+    d = scenes.synthetic_hall()
+    tris = np.concatenate([m["positions"][m["indices"]].reshape(-1, 9) for m in d["meshes"]])
+    assert len(tris) == d["triangles"] == 12382
+    for mode in ("dp", "greedy"):
+        out = run(bvh_check, tmp_path, tris, 20000, mode, eye=d["camera"]["origin"])
+        assert out["triangles"] == 12382 and out["mismatches"] == 0 and out["bad_refs"] == 0 and out["hits"] > 15000, out

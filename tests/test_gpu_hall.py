@@ -1,0 +1,84 @@
+"""-m gpu: HIP path vs the CPU oracle on a MIXED-SCALE scene (scenes.synthetic_hall: walls of two triangles each, 12 000 centimetre-sized triangles in one corner,
+slivers through the whole volume, 120 coincident triangles, nested triangles) — what the uniformly tessellated stand-ins of the bench do not exercise: leaves that
+overlap at very different scales, equal hit distances (the tie goes to the lowest primitive id), long thin boxes."""
+import numpy as np
+import pytest
+
+import loupiote_amd as lp
+from loupiote_amd import scenes, testing as T
+from oracle import harness
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the arms of tests/conftest.py PIPELINES
+
+
+@pytest.fixture(scope="module")
+def hall():
+    from oracle import orc
+    desc = scenes.synthetic_hall()
+    return desc, orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
+
+
+def _render(device, desc, size, depth, frames, options=None, shard=None):
+    sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
+    pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+    r = lp.Renderer(device, size)
+    r.downsample_factor = 1.0
+    r.resize(device, sg, pr, size)
+    r.set_max_bounces(depth)
+    r.set_vfov(T.VFOV)
+    for k, v in (options or {}).items():
+        r.set_option(k, v)
+    if shard:
+        r.set_shard(*shard)
+        r.set_resources(device, sg, pr)
+    r.reset_accumulation()
+    r.accumulate = True
+    r.reset_ray_counts()
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    for _ in range(frames):
+        r.raytrace(view)
+    img, c = r.read_radiance(), r.ray_counts()
+    r.close(); pr.close(); sg.close()
+    return img, (c.closest, c.shadow, c.shaded)
+
+
+@pytest.mark.parametrize("size,depth,frames", [((160, 90), 6, 2), ((384, 216), 8, 1)])
+def test_hall_frames_equal_the_oracle(device, hall, size, depth, frames):
+    from oracle import orc
+    desc, osc = hall
+    view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+    acc, oc = osc.render(size[0], size[1], view, T.VFOV, depth, frames=frames, want_counters=True)
+    img, counts = _render(device, desc, size, depth, frames)
+    assert counts == (oc.closest, oc.shadow, oc.shaded)
+    assert img.tobytes() == orc.resolve(acc).tobytes()
+
+
+def test_hall_shards_add_up_to_the_whole_frame(device, hall):
+    desc, _ = hall
+    whole, counts = _render(device, desc, (320, 184), 6, 2)
+    acc = np.zeros_like(whole)
+    tot = np.zeros(3, np.int64)
+    for rank in range(3):
+        part, c = _render(device, desc, (320, 184), 6, 2, shard=(rank, 3))
+        acc += part
+        tot += np.asarray(c, np.int64)
+    assert acc.tobytes() == whole.tobytes() and tuple(int(x) for x in tot) == counts
+
+
+def test_hall_rays_from_inside_the_gravel_and_along_the_slivers(device, hall):
+    """closest-hit and any-hit queries (lpt_trace_closest / lpt_trace_occluded) against the oracle's brute force: origins inside the pile of tiny triangles, directions along the walls"""
+    desc, osc = hall
+    rng = np.random.default_rng(11)
+    n = 6000
+    o = np.concatenate([rng.uniform((-7.5, 0.05, -7.5), (-4.5, 1.5, -4.5), (n // 2, 3)), rng.uniform((-7.9, 0.1, -7.9), (7.9, 8.9, 7.9), (n - n // 2, 3))]).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 4, 1] *= 0.02                                   # grazing along the floor
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
+    got, want = sg.trace_closest(o, d), osc.trace_closest(o, d, brute_force=True)
+    assert np.array_equal(got["prim"], want["prim"]) and (got["prim"] != 0xFFFFFFFF).mean() > 0.9
+    for k in ("t", "u", "v"):
+        assert got[k].tobytes() == want[k].tobytes()
+    tmax = rng.uniform(0.05, 12.0, n).astype(np.float32)
+    assert np.array_equal(sg.trace_occluded(o, d, tmax), osc.trace_occluded(o, d, tmax, brute_force=True))
+    sg.close()
