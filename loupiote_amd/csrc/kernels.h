@@ -2197,14 +2197,21 @@ __global__ __launch_bounds__(kBlock) void k_debug_view(const uint4 *gb, const fl
     }
 }
 
-__global__ void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces, uint32_t packet_primary) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (packet_primary) { tot->primary += QC(ctr, 0); tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
+// one wave: lane b gathers bounce b's counts (kMaxBounces = 64 lanes), a shuffle reduction adds them up — one thread walking 90 dependent loads took 15 us
+// at the end of every wavefront
+__global__ __launch_bounds__(64) void k_finish_frame(FrameCounters *ctr, Totals *tot, uint32_t bounces, uint32_t packet_primary) {
+    static_assert(kMaxBounces <= 64, "a lane per bounce");
+    if (blockIdx.x != 0) return;
+    const uint32_t b = threadIdx.x;
     unsigned long long c = 0, s = 0, sh = 0;
-    for (uint32_t b = 0; b < bounces; ++b) {
-        c += QC(ctr, b); s += SC(ctr, b); sh += ctr->shaded[b];
+    if (b < bounces) {
+        c = QC(ctr, (int)b); s = SC(ctr, (int)b); sh = ctr->shaded[b];
         for (uint32_t k = 0; k < 8u; ++k) sh += ctr->shaded_part[(b * 8u + k) * 32u];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); s += __shfl_xor(s, off); sh += __shfl_xor(sh, off); }
+    if (b != 0) return;
+    if (packet_primary) { tot->primary += QC(ctr, 0); tot->packet_nodes += ctr->packet_nodes; tot->packet_tris += ctr->packet_tris; }
     tot->closest += c; tot->shadow += s; tot->shaded += sh; tot->nodes += ctr->nodes; tot->tris += ctr->tris;
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;

@@ -1,26 +1,23 @@
 #!/bin/bash
-# the tail finished in place (LPT_OPT_TAIL_LANES) on the 1/8 shard, span form: tools/dev/r05_tail_ab.sh <out>
+# finer A/B of LPT_OPT_TAIL_LANES: 1/8 and 1/4 shards, and whole small frames (path_rays 0: the per-bounce launches): tools/dev/r05_tail_ab.sh <out>
 OUT=gpurun_out/$1
 mkdir -p $OUT
-run() {  # name, bench args...
+run() {
   local name=$1; shift
-  timeout 400 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extras "$@" > $OUT/$name.json 2> $OUT/$name.err
+  timeout 400 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras "$@" > $OUT/$name.json 2> $OUT/$name.err
   python - <<PY
 import json
 try:
     j = json.loads(open("$OUT/$name.json").read().strip().splitlines()[-1])
-    print("$name: %.3f ms/frame  stages %s  checksum %r" % (j["ms_per_frame"], {k: round(x, 3) for k, x in j["stage_ms_per_frame"].items() if x}, j["config"]["frame_checksum"]))
+    print("$name: %.3f ms/frame  trace %.3f shadow %.3f shade %.3f  checksum %r" % (j["ms_per_frame"], j["stage_ms_per_frame"]["intersection"], j["stage_ms_per_frame"]["shadow"], j["stage_ms_per_frame"]["shading"], j["config"]["frame_checksum"]))
 except Exception as e:
     print("$name: FAILED", e); print(open("$OUT/$name.err").read()[-800:])
 PY
 }
-for rep in 1 2; do
-  run sh8_base_$rep --emulate-shard 8
-  run sh8_nobudget_$rep --emulate-shard 8 --opt step_budget=0
-  for t in 1 2 3 4 6 8; do run sh8_tail${t}_$rep --emulate-shard 8 --opt tail_lanes=$t; done
+for rep in 1 2 3; do
+  for t in 0 2 3 4 5; do run sh8_t${t}_$rep --emulate-shard 8 --opt tail_lanes=$t; done
 done
-run sh4_base --emulate-shard 4
-run sh4_tail2 --emulate-shard 4 --opt tail_lanes=2
-run sh4_tail4 --emulate-shard 4 --opt tail_lanes=4
-run full_base
-run full_tail4 --opt tail_lanes=4 --opt budget_rays=2000000000 --opt budget_split=1
+for t in 0 3 4; do run sh4_t${t} --emulate-shard 4 --opt tail_lanes=$t; done
+for t in 0 3 4; do run sh16_t${t} --emulate-shard 16 --opt tail_lanes=$t; done
+for t in 0 3 4; do run f480_t${t} --width 480 --height 270 --opt path_rays=0 --opt pool_rays=0 --opt tail_lanes=$t; done
+for t in 0 3 4; do run f960_t${t} --width 960 --height 540 --opt path_rays=0 --opt pool_rays=0 --opt tail_lanes=$t; done
