@@ -555,8 +555,8 @@ typedef enum lpt_option {
     LPT_OPT_SHADE_BLOCKS_PER_CU = 7,/* shading pass: blocks per CU (default 4) */
     LPT_OPT_PATH_RAYS = 8,          /* wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (the
                                      * path kernel: no chip-wide barrier per bounce — small frames and the tile shards of a wide multi-GPU
-                                     * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 450 000, the
-                                     * measured cross-over; 0: never */
+                                     * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 120 000, the
+                                     * measured cross-over (450 000 before the tails of those launches were finished in place); 0: never */
     LPT_OPT_PATH_WAVES_PER_CU = 9,  /* path kernel: persistent waves per CU (default 16) */
     LPT_OPT_PATH_REFILL = 10,       /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
     LPT_OPT_OCC_CELL_MILLI = 11,    /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */

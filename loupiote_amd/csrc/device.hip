@@ -172,7 +172,8 @@ constexpr int kMaxLanes = 4;
 constexpr uint32_t kStepBudget = 48u, kBudgetRays = 3000000u;  // defaults of LPT_OPT_STEP_BUDGET / LPT_OPT_BUDGET_RAYS (measured: profiles/r04_experiments_ab.txt H)
 constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to this angle per pixel (measured: 1.53 mrad, 960x540: packets 4.46 against 4.51 ms; 2.05 mrad, 720x405: 3.32 against 3.20)
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
-constexpr uint32_t kPathRays = 450000u;           // rays of a wavefront up to which the path kernel is used: measured cross-over against the per-bounce launches WITH their step budget
+constexpr uint32_t kPathRays = 120000u;           // rays of a wavefront up to which the path kernel is used: the measured cross-over against the per-bounce launches with their tails in place
+                                                  // (whole frames, ms: 113 k rays 0.913 path / 0.932 per bounce, 147 k 1.07 / 0.99, 332 k 1.89 / 1.40; it was 450 000 against the budget pair)
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
 constexpr uint32_t kCoopWavesPerCu = 32u;   // k_trace_coop's grid: a wave per straggler, most waves find none and leave (8 / 4 per CU: the same 2.90 ms per 1/8-shard frame, round 5)
 constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
