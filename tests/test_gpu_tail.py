@@ -112,3 +112,24 @@ def test_config4_at_full_size_and_its_eighth_shard_with_the_tail_in_place(device
     own = shard[0][0][..., 3] != 0.0      # the pixels rank 3 owns (the others stay zero in its buffer)
     assert own.any() and np.array_equal(shard[0][0][own], img[own])
     pr.close(); sg.close()
+
+
+def test_random_frames_with_and_without_the_tail_are_the_same_frame(device):
+    """differential: 36 random frame sizes / depths / sample counts / refill thresholds / waves per CU / tail widths / shards on the mixed-scale hall and the atrium;
+    every frame equals the one the plain per-lane launches give (no tail, no step budget), bit for bit, with equal ray counts (tools/dev/r05_tail_fuzz.py runs more)"""
+    rng = np.random.default_rng(17)
+    base = dict(PER_BOUNCE, step_budget=0, tail_lanes=0)
+    for desc in (scenes.synthetic_hall(), scenes.synthetic_atrium(texture_size=64)):
+        sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
+        pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+        view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+        for _ in range(18):
+            size = (int(rng.integers(17, 360)), int(rng.integers(9, 220)))
+            depth, spp = int(rng.integers(1, 9)), int(rng.integers(1, 6))
+            opts = dict(base, tail_lanes=int(rng.integers(1, 9)), refill=int(rng.integers(0, 64)), trace_waves_per_cu=int(rng.choice([0, 1, 2, 5, 24, 32])),
+                        pipe_rays=int(rng.choice([0, 0x7FFFFFFF])), packet_primary=int(rng.integers(0, 3)))
+            shard = None if rng.random() < 0.6 else (int(rng.integers(0, 3)), 3)
+            ref = _render(device, sg, pr, size, depth, spp, base, view, shard=shard)
+            got = _render(device, sg, pr, size, depth, spp, opts, view, shard=shard)
+            assert got[1] == ref[1] and got[0].tobytes() == ref[0].tobytes(), (desc["name"], size, depth, spp, shard, opts)
+        pr.close(); sg.close()
