@@ -133,3 +133,23 @@ def test_random_frames_with_and_without_the_tail_are_the_same_frame(device):
             got = _render(device, sg, pr, size, depth, spp, opts, view, shard=shard)
             assert got[1] == ref[1] and got[0].tobytes() == ref[0].tobytes(), (desc["name"], size, depth, spp, shard, opts)
         pr.close(); sg.close()
+
+
+def test_tail_on_the_trees_of_the_gpu_builder(device):
+    """the LBVH builder's trees (Morton order, collapsed to 8-wide on the GPU; depth 8 / 11 here against the host builder's 8 / 10): other stacks to expand into the walk's
+    node column, other leaves.  Frames with the tail equal the frames without it — and the host-built tree's frames: only the Woop test decides hits"""
+    for desc in (scenes.synthetic_hall(), scenes.synthetic_atrium(texture_size=64)):
+        view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
+        pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
+        frames = {}
+        for gpu_build in (False, True):
+            sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device, gpu_build=gpu_build)
+            depth = sg.stats().max_depth
+            for tail in (0, 1, 4, 8):
+                frames[(gpu_build, tail)] = _render(device, sg, pr, (200, 120), 6, 2, dict(PER_BOUNCE, step_budget=0, tail_lanes=tail, trace_waves_per_cu=2), view)
+            print("%s: %s tree depth %d" % (desc["name"], "GPU-built" if gpu_build else "host-built", depth))
+            sg.close()
+        ref = frames[(False, 0)]
+        for key, got in frames.items():
+            assert got[1] == ref[1] and got[0].tobytes() == ref[0].tobytes(), (desc["name"], key)
+        pr.close()
