@@ -175,6 +175,7 @@ constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, 
 constexpr uint32_t kPathRays = 120000u;           // rays of a wavefront up to which the path kernel is used: the measured cross-over against the per-bounce launches with their tails in place
                                                   // (whole frames, ms: 113 k rays 0.913 path / 0.932 per bounce, 147 k 1.07 / 0.99, 332 k 1.89 / 1.40; it was 450 000 against the budget pair)
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
+constexpr uint32_t kPacketBlocksPerCu = 128u;   // k_trace_packet's grid: one-wave blocks, packets dealt by stride (32 / 64 per CU: the same, round 5)
 constexpr uint32_t kCoopWavesPerCu = 32u;   // k_trace_coop's grid: a wave per straggler, most waves find none and leave (8 / 4 per CU: the same 2.90 ms per 1/8-shard frame, round 5)
 constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
@@ -1771,8 +1772,8 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 // 4 samples of a 4x4-pixel quarter per packet instead of one sample of an 8x8 patch, where the queue order allows it: a dense frame
                 // (queue index = sample * slots + slot), 8x8 pixel blocks inside the tiles, whole blocks, a multiple of four samples
                 const uint32_t quad_slots = (r->packet_quads && dense && p.block8 && p.n_slots % 64u == 0u && p.slot0 % 64u == 0u && n_samples % 4u == 0u) ? p.n_slots : 0u;
-                if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
-                else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * 128u)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
+                if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
+                else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 stage_end(r, s);
             } else if (!(r->path_rays && n_rays <= r->path_rays) && !use_pool) trace(0, -1);   // a path- or pool-kernel wavefront traces its primary rays itself
         }
