@@ -562,7 +562,8 @@ typedef enum lpt_option {
     LPT_OPT_OCC_CELL_MILLI = 11,    /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
     LPT_OPT_STEP_BUDGET = 12,       /* per-bounce traversal launches: a ray not finished after this many steps is dropped by the per-lane kernel and traced
                                      * again by a whole wave (k_trace_coop: eight lanes per node), so that the one ray in 10^5 that needs hundreds of steps
-                                     * does not set the duration of the launch; default 48, 0 = off.  Not applied while lpt_renderer_enable_stats is on */
+                                     * does not set the duration of the launch; default 48, 0 = off.  Not applied while lpt_renderer_enable_stats is on, and only where
+                                     * LPT_OPT_TAIL_LANES is 0 (the tail finished in place, the default, leaves nothing to drop) */
     LPT_OPT_BUDGET_RAYS = 13,       /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
                                      * value applies the budget to every wavefront up to it) */
     LPT_OPT_PACKET_QUADS = 14,      /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
