@@ -245,7 +245,7 @@ struct lpt_renderer {
     // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
     bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
-    // the same launches' tails finished IN PLACE instead (kernels.h trace_tail): a wave whose queues are dry and that is down to this many live rays finishes them
+    // the same launches' tails finished IN PLACE instead (kernels.h tail_park / tail_walk): a wave whose queues are dry and that is down to this many live rays finishes them
     // cooperatively from where they stand (default); 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
     uint32_t tail_lanes = 4u;      // 1/8 shard of the bench frame: 3, 4, 5 the same (2.74 ms per frame against 2.90 with the budget pair), 2 and 8 slower
     uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
@@ -1735,7 +1735,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // (not with the stats kernels: a ray dropped at the budget would be missing from the steps-per-ray histogram and its partial node / triangle counts would be
         // counted again by the cooperative kernel's full re-trace — ADVICE r04)
         const bool tail_launch = !r->stats && (solo || r->budget_split) && n_rays <= r->budget_rays;
-        // ... the tail finished in place (trace_tail) comes first where it is on: nothing is dropped then, so there is nothing to re-trace
+        // ... the tail finished in place (tail_walk) comes first where it is on: nothing is dropped then, so there is nothing to re-trace
         const uint32_t tail = tail_launch ? std::min(std::min(r->tail_lanes, kTailMax), (uint32_t)std::max(r->refill, 0)) : 0u;
         const uint32_t budget = (tail_launch && !tail && r->step_budget) ? r->step_budget : 0u;
         const size_t tail_lds = tail ? sizeof(uint32_t) * tail_lds_words(r->sg->stats.max_depth) : 0u;

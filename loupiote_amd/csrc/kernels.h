@@ -856,13 +856,13 @@ __device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3
     }
 }
 
-// THE TAIL OF A TRAVERSAL LAUNCH, IN PLACE.  A launch lasts as long as its last ray, and a lane takes one dependent step (~1.3 us) per node.
+// THE TAIL OF A TRAVERSAL LAUNCH, IN PLACE.  A launch lasts as long as its last ray, and a lane takes one dependent step (2-3 us with every wave resident) per node.
 // A wave whose queues are dry and that is down to `tail` live rays or fewer stops stepping them lane by lane and finishes them one after the other with all 64
 // lanes, each from where its lane stands: the ray's frontier — the node groups on the lane's LDS stack and the one in hand, expanded to node indices — seeds the
 // cooperative walk above, the triangle groups the lane still holds are tested first, the best hit so far carries over.  Nothing is restarted at the root and
-// no second launch is needed (the step budget + k_trace_coop pair this replaces: 48 steps thrown away per straggler, ~15 us of launch per bounce).
+// no second launch is needed (the step budget + k_trace_coop pair this replaces: 48 steps thrown away per straggler, ~19 us of launch per bounce).
 // `columns` = the wave's per-lane stacks (entry e of lane L at columns[e * kTraceBlock + L]); `tail_lds` = tail_lds_words(depth) words behind them: the live
-// rays' states first (parked there so that the per-lane state's registers are free during the walks: the kernel keeps its 78 VGPRs), then the node column.
+// rays' states first (parked there so that the per-lane state's registers are free during the walks: 80 VGPRs, still 6 waves per SIMD), then the node column.
 constexpr uint32_t kTailMax = 8u;          // rays a wave finishes this way at most (one after the other: beyond a handful the per-lane steps are faster)
 constexpr uint32_t kTailStateWords = 20u;  // five 16-byte rows per ray
 __host__ __device__ __forceinline__ uint32_t tail_lds_words(uint32_t tree_depth) { return kTailMax * kTailStateWords + coop_stack_entries(kTailStack, tree_depth); }
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
                 if (use_s) ps.next = adv; else pc.next = adv;
             } else if (n_active == 0) break;
             else if (TAIL && n_active <= (int)tail) {
-                // both queues are dry and few rays are left: the wave finishes them cooperatively, in place (trace_tail; the host sets `tail` only without the stats)
+                // both queues are dry and few rays are left: the wave finishes them cooperatively, in place (tail_park / tail_walk; the host sets `tail` only without the stats)
                 TailArgs ta = {sc.nodes, sc.woop, sc.leaf_prim, sc.lights, sc.n_lights, sc.stack_entries, 0u, hits, sq.c, Lsum};
                 ta.n_live = tail_park<PIPE>(rs, amask, active, shadow, ray, reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2)));
                 tail_walk(ta);
