@@ -582,10 +582,14 @@ typedef enum lpt_option {
     LPT_OPT_SPLIT_RAYS = 20,        /* a batch above this many rays that would still fit one wavefront leaves as two, on the renderer's lanes (default
                                      * 3 000 000; 0: never split below LPT_OPT_WAVEFRONT_RAYS) */
     LPT_OPT_BUDGET_SPLIT = 21,      /* 1: the step budget also applies to the pieces of a cut batch (default 0: only to submissions that leave as one wavefront) */
-    LPT_OPT_TAIL_LANES = 22         /* the same launches' tails finished IN PLACE: a wave of the per-lane kernel whose queues are dry and that is down to this
+    LPT_OPT_TAIL_LANES = 22,        /* the same launches' tails finished IN PLACE: a wave of the per-lane kernel whose queues are dry and that is down to this
                                      * many live rays (1..8) finishes them cooperatively, all 64 lanes per ray, from where each stands — nothing is
                                      * dropped, restarted at the root or launched behind.  Default 4; 0 = off, and LPT_OPT_STEP_BUDGET applies instead.  Like the budget, not used while
                                      * lpt_renderer_enable_stats is on */
+    LPT_OPT_COOP_RAYS = 23          /* wavefronts of at most this many rays — fewer than the chip has wave slots — take the per-bounce launches with EVERY ray
+                                     * traced by a whole wave (eight lanes per node): the frame of a tiny wavefront is a chain of dependent traversal steps,
+                                     * and a wave per ray shortens it several times over (64x36 pixels, 4 spp: 0.72 -> 0.39 ms per frame).  Default 32 000, the measured cross-over;
+                                     * 0 = never.  Not used while lpt_renderer_enable_stats is on */
 } lpt_option;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);

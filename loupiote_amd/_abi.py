@@ -22,7 +22,7 @@ COMM_ID_BYTES = 128
 # lpt_option (include/lpt.h): launch tuning behind lpt_renderer_set_option; every value gives the same frame
 OPTIONS = {"merge_trace": 1, "packet_primary": 2, "pipe_rays": 3, "wavefront_rays": 4, "refill": 5, "trace_waves_per_cu": 6,
            "shade_blocks_per_cu": 7, "path_rays": 8, "path_waves_per_cu": 9, "path_refill": 10, "occ_cell_milli": 11, "step_budget": 12, "budget_rays": 13, "packet_quads": 14,
-           "pool_rays": 15, "pool_shaders": 16, "pool_entries": 17, "pool_waves": 18, "pool_refill": 19, "split_rays": 20, "budget_split": 21, "tail_lanes": 22}
+           "pool_rays": 15, "pool_shaders": 16, "pool_entries": 17, "pool_waves": 18, "pool_refill": 19, "split_rays": 20, "budget_split": 21, "tail_lanes": 22, "coop_rays": 23}
 EXCHANGE_GATHER_TILES = 0
 HOST_FRAME_HOST_ONLY = 1
 EXCHANGE_REDUCE = 1

@@ -175,6 +175,8 @@ constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, 
 constexpr uint32_t kPathRays = 120000u;           // rays of a wavefront up to which the path kernel is used: the measured cross-over against the per-bounce launches with their tails in place
                                                   // (whole frames, ms: 113 k rays 0.913 path / 0.932 per bounce, 147 k 1.07 / 0.99, 332 k 1.89 / 1.40; it was 450 000 against the budget pair)
 constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
+constexpr uint32_t kCoopRays = 32000u;            // rays of a wavefront up to which EVERY ray is traced by a whole wave (k_trace_coop over the queues): the measured cross-over (28 k rays:
+                                                  // 0.755 -> 0.652 ms per frame, 37 k: 0.765 -> 0.787; profiles/r05_experiments_ab.txt V)
 constexpr uint32_t kPacketBlocksPerCu = 128u;   // k_trace_packet's grid: one-wave blocks, packets dealt by stride (32 / 64 per CU: the same, round 5)
 constexpr uint32_t kCoopWavesPerCu = 32u;   // k_trace_coop's grid: a wave per straggler, most waves find none and leave (8 / 4 per CU: the same 2.90 ms per 1/8-shard frame, round 5)
 constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
@@ -247,6 +249,7 @@ struct lpt_renderer {
     bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
     // the same launches' tails finished IN PLACE instead (kernels.h tail_park / tail_walk): a wave whose queues are dry and that is down to this many live rays finishes them
     // cooperatively from where they stand (default); 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
+    uint32_t coop_rays = kCoopRays;   // LPT_OPT_COOP_RAYS
     uint32_t tail_lanes = 4u;      // 1/8 shard of the bench frame: 3, 4, 5 the same (2.74 ms per frame against 2.90 with the budget pair), 2 and 8 slower
     uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
     // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
@@ -1465,6 +1468,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_SPLIT_RAYS: r->split_rays = value; break;
     case LPT_OPT_BUDGET_SPLIT: r->budget_split = value != 0; break;
     case LPT_OPT_TAIL_LANES: r->tail_lanes = (uint32_t)std::min<uint64_t>(value, kTailMax); break;
+    case LPT_OPT_COOP_RAYS: r->coop_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1494,6 +1498,7 @@ int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) 
     case LPT_OPT_SPLIT_RAYS: *value = r->split_rays; break;
     case LPT_OPT_BUDGET_SPLIT: *value = r->budget_split; break;
     case LPT_OPT_TAIL_LANES: *value = r->tail_lanes; break;
+    case LPT_OPT_COOP_RAYS: *value = r->coop_rays; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
     }
     return LPT_OK;
@@ -1739,10 +1744,19 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const uint32_t tail = tail_launch ? std::min(std::min(r->tail_lanes, kTailMax), (uint32_t)std::max(r->refill, 0)) : 0u;
         const uint32_t budget = (tail_launch && !tail && r->step_budget) ? r->step_budget : 0u;
         const size_t tail_lds = tail ? sizeof(uint32_t) * tail_lds_words(r->sg->stats.max_depth) : 0u;
+        // a TINY wavefront (fewer rays than the chip has wave slots): the per-bounce launches with EVERY ray traced by a whole wave (k_trace_coop over the queues) — a lane per
+        // ray leaves the chip empty and the frame is one chain of dependent steps (64x36, 4 spp: k_path 0.72 ms per frame, the per-lane launches 0.83, this 0.39)
+        const bool coop_all = r->merge_trace && !r->stats && r->coop_rays && n_rays <= r->coop_rays;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
             const int launch_no = cb >= 0 ? cb : (int)nb;   // which strag_count[] this launch fills
+            if (coop_all) {
+                const size_t clds = sizeof(uint32_t) * coop_stack_entries(kCoopStack, r->sg->stats.max_depth);
+                hipLaunchKernelGGL(k_trace_coop<false>, dim3(std::min(2u * n_rays, cus * kCoopWavesPerCu)), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, (const uint32_t *)nullptr, launch_no);
+                stage_end(r, s);
+                return;
+            }
             if (tail) {
                 if (pipe) hipLaunchKernelGGL((k_trace<false, true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
                 else hipLaunchKernelGGL((k_trace<false, false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
@@ -1762,7 +1776,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // (traversal stacks of every wave + the rings) must fit the CU's 160 KB — a tree too deep for that takes the per-bounce launches
         const uint32_t pool_entries = r->pool_entries ? r->pool_entries : 256u * r->pool_waves, pool_trace_cap = 64u * r->pool_waves;
         const uint32_t pool_lds = pool_lds_bytes(sc.stack_entries, r->pool_waves, pool_entries, pool_trace_cap);
-        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && pool_lds * (16u / r->pool_waves) <= 160u * 1024u;
+        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && !coop_all && pool_lds * (16u / r->pool_waves) <= 160u * 1024u;
         if (r->merge_trace) {
             if (packet) {
                 // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
@@ -1775,11 +1789,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 stage_end(r, s);
-            } else if (!(r->path_rays && n_rays <= r->path_rays) && !use_pool) trace(0, -1);   // a path- or pool-kernel wavefront traces its primary rays itself
+            } else if (coop_all || (!(r->path_rays && n_rays <= r->path_rays) && !use_pool)) trace(0, -1);   // a path- or pool-kernel wavefront traces its primary rays itself
         }
         // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
         // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
-        const bool path = r->merge_trace && r->path_rays && n_rays <= r->path_rays;   // the primary hits are there, whichever kernel found them
+        const bool path = r->merge_trace && r->path_rays && n_rays <= r->path_rays && !coop_all;   // the primary hits are there, whichever kernel found them
         if (path) {
             stage_begin(r, ST_PATH, s);
             const uint32_t pblocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), std::max(8u, (cus * r->path_waves_per_cu) & ~7u));

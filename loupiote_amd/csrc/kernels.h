@@ -1111,18 +1111,21 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
     }
 }
 
-// The stragglers of a traversal launch (k_trace with a step budget), each traced again from the root by a WHOLE WAVE (coop_walk above): a ray that would
-// take a lane 100-360 dependent steps takes the wave 15-40 rounds.  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
+// The stragglers of a traversal launch (k_trace with a step budget) — or every ray of a tiny wavefront —, each traced from the root by a WHOLE WAVE (coop_walk
+// above): a ray that would take a lane 100-360 dependent steps takes the wave 15-40 rounds.  Closest-hit rays of queue `cb`, shadow rays of queue `sb`.
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, float4 *hits, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr,
                                                             int cb, int sb, const uint32_t *strag, int launch) {
     static_assert(kTraceBlock == 64, "one wave per block: the LDS stack is the wave's");
     uint32_t *stk = reinterpret_cast<uint32_t *>(lds_dyn);   // coop_stack_entries(kCoopStack, depth) node indices (host)
     const uint32_t lane = threadIdx.x;
-    const uint32_t n_strag = ctr->strag_count[launch];
+    // strag == nullptr: EVERY ray of the two queues, closest-hit rays first — a wavefront with fewer rays than the chip has wave slots (LPT_OPT_COOP_RAYS): a lane
+    // per ray would leave the chip empty and make the frame one long chain of dependent steps; a wave per ray shortens the chain several times over
+    const uint32_t n_closest = strag ? 0u : (cb < 0 ? 0u : QC(ctr, cb));
+    const uint32_t n_strag = strag ? ctr->strag_count[launch] : n_closest + (sb < 0 ? 0u : SC(ctr, sb));
     uint32_t n_nodes = 0, n_tris = 0, s_nodes = 0, s_tris = 0;
     for (uint32_t si = blockIdx.x; si < n_strag; si += gridDim.x) {
-        const uint32_t e = strag[si];
+        const uint32_t e = strag ? strag[si] : (si < n_closest ? si : ((si - n_closest) | 0x80000000u));
         const bool shadow = (e >> 31) != 0u;
         const uint32_t ray = e & 0x7FFFFFFFu;
         const float4 o4 = shadow ? sq.o[ray] : q.o[ray], d4 = shadow ? sq.d[ray] : q.d[ray];

@@ -274,7 +274,9 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
                 {"path_rays": 0, "step_budget": 12, "pipe_rays": 0, "tail_lanes": 0},
                 {"path_rays": 0, "step_budget": 3, "budget_rays": 10, "tail_lanes": 0},
                 # the shipped form of the same launches: tails finished in place (tests/test_gpu_tail.py)
-                {"path_rays": 0, "tail_lanes": 4}, {"path_rays": 0, "tail_lanes": 8, "pipe_rays": 0})
+                {"path_rays": 0, "tail_lanes": 4}, {"path_rays": 0, "tail_lanes": 8, "pipe_rays": 0},
+                # a wave per ray for every ray of the wavefront (the form tiny wavefronts take by themselves: tests/test_gpu_coop_all.py)
+                {"coop_rays": 0x7FFFFFFF}, {"coop_rays": 0x7FFFFFFF, "packet_primary": 1}, {"coop_rays": 0})
     for opts in variants:
         r = _renderer(device, sg, pr, 0, options=opts)
         assert all(r.get_option(k) == v for k, v in opts.items())
