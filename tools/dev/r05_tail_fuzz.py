@@ -13,6 +13,7 @@ import loupiote_amd as lp  # noqa: E402
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+mode = sys.argv[3] if len(sys.argv) > 3 else "tail"   # "coop": small frames, a wave per ray (forced / as shipped) against the plain per-lane launches
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 dev = lp.Device(0)
 world = []
@@ -47,15 +48,18 @@ for k in range(cases):
     desc, sg, pr = world[k % len(world)]
     size = (int(rng.integers(17, 420)), int(rng.integers(9, 260)))
     depth, spp, frames = int(rng.integers(1, 9)), int(rng.integers(1, 6)), int(rng.integers(1, 3))
-    base = {"path_rays": 0, "pool_rays": 0, "step_budget": 0, "tail_lanes": 0}
+    base = {"path_rays": 0, "pool_rays": 0, "step_budget": 0, "tail_lanes": 0, "coop_rays": 0}
     opts = dict(base, tail_lanes=int(rng.integers(1, 9)), refill=int(rng.integers(0, 64)), trace_waves_per_cu=int(rng.choice([0, 1, 2, 5, 24, 32])),
                 pipe_rays=int(rng.choice([0, 0x7FFFFFFF])), packet_primary=int(rng.integers(0, 3)), wavefront_rays=int(rng.choice([4194304, 20000, 70000])))
+    if mode == "coop":
+        size = (int(rng.integers(9, 200)), int(rng.integers(5, 120)))
+        opts = dict({} if rng.random() < 0.5 else {"coop_rays": 0x7FFFFFFF}, packet_primary=int(rng.integers(0, 3)), wavefront_rays=int(rng.choice([4194304, 5000, 30000])))
     shard = None if rng.random() < 0.6 else (int(rng.integers(0, 3)), 3)
     ref = render(desc, sg, pr, size, depth, spp, frames, base, shard)
     got = render(desc, sg, pr, size, depth, spp, frames, opts, shard)
     ok = ref == got
     bad += 0 if ok else 1
     if not ok or k % 20 == 0:
-        print("%3d %-28s %4dx%-4d depth %d spp %d frames %d shard %s %s -> %s %s" % (k, desc["name"][:28], size[0], size[1], depth, spp, frames, shard, {a: b for a, b in opts.items() if a not in base or a == "tail_lanes"}, "identical" if ok else "DIFFERENT", got[1]), flush=True)
-print("tail fuzz: %d cases, %d different" % (cases, bad))
+        print("%3d %-28s %4dx%-4d depth %d spp %d frames %d shard %s %s -> %s %s" % (k, desc["name"][:28], size[0], size[1], depth, spp, frames, shard, {a: b for a, b in opts.items() if a not in base or a in ("tail_lanes", "coop_rays")}, "identical" if ok else "DIFFERENT", got[1]), flush=True)
+print("%s fuzz: %d cases, %d different" % (mode, cases, bad))
 sys.exit(1 if bad else 0)
