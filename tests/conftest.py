@@ -43,15 +43,16 @@ def device():
 PIPELINES = {
     # every bounce behind the primary hits in ONE launch, a lane carries a path (k_path), whatever the size of the wavefront; bounce 0 through the packet
     # kernel at every resolution (the default picks it by pixel footprint: not for the small frames most tests render)
-    "path": {"path_rays": 0x7FFFFFFF, "packet_primary": 1},
+    "path": {"path_rays": 0x7FFFFFFF, "packet_primary": 1, "coop_rays": 0},
     # the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace) with a step budget of 16 (default 48), so that in every parity test a good part of the
     # rays is finished by the wave-cooperative kernel (k_trace_coop) and the rest by the per-lane kernel; the packet choice is the library's.  tail_lanes 0: the
     # shipped form of these launches — tails finished in place instead of a budget — runs in the "default" arm (where the frame takes the per-bounce launches) and
     # in tests/test_gpu_tail.py
-    "per_bounce": {"path_rays": 0, "step_budget": 16, "tail_lanes": 0},
+    "per_bounce": {"path_rays": 0, "step_budget": 16, "tail_lanes": 0, "coop_rays": 0},
     # round 5: the CU-local pool of trace and shade work (k_pool): records handed between the waves of a block through LDS rings, hits shaded by kind
-    "pool": {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "packet_primary": 1},
-    # the configuration as shipped: nothing forced (kernel choice by ray count and pixel footprint, default budget, quad packets) — ADVICE r04
+    "pool": {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "packet_primary": 1, "coop_rays": 0},
+    # the configuration as shipped: nothing forced (kernel choice by ray count and pixel footprint — a wave per ray for the tiny frames many tests render, LPT_OPT_COOP_RAYS —,
+    # tails in place, quad packets) — ADVICE r04.  The other arms switch the tiny-wavefront rule off (coop_rays 0) so that they exercise the kernel they name at every size
     "default": {},
 }
 

@@ -167,6 +167,6 @@ def test_step_budget_and_the_cooperative_kernel_give_the_same_frame(device, atri
     from oracle import orc
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
     acc, oc = osc.render(160, 90, view, T.VFOV, 6, frames=2, want_counters=True)
-    img, c, _ = render_desc(device, desc, 160, 90, 6, 2, options={"path_rays": 0, "step_budget": budget, "tail_lanes": 0})
+    img, c, _ = render_desc(device, desc, 160, 90, 6, 2, options={"path_rays": 0, "step_budget": budget, "tail_lanes": 0, "coop_rays": 0})
     assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded)
     assert img.tobytes() == orc.resolve(acc).tobytes()

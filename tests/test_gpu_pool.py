@@ -12,7 +12,7 @@ from oracle import harness
 
 pytestmark = pytest.mark.gpu
 W, H, DEPTH = 203, 117, 5
-POOL = {"path_rays": 0, "pool_rays": 0x7FFFFFFF}
+POOL = {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "coop_rays": 0}   # coop_rays 0: small wavefronts would otherwise be traced a wave per ray
 
 
 @pytest.fixture(scope="module")

@@ -14,7 +14,7 @@ from oracle import harness
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PER_BOUNCE = {"path_rays": 0, "pool_rays": 0}
+PER_BOUNCE = {"path_rays": 0, "pool_rays": 0, "coop_rays": 0}   # coop_rays 0: the tiny-wavefront rule (a wave per ray) would take the small frames here
 
 
 @pytest.fixture(scope="module")
