@@ -700,6 +700,8 @@ def run(args):
             # what the span pays for its read-back: the read that ends a frame submits it and copies every wavefront's rows as soon as they are
             # final (include/lpt.h lpt_renderer_read_radiance), so part of `median_ms` hides under the wavefronts that are still tracing
             readback["exposed_in_span_ms"] = elapsed / n_frames * 1e3 - latency["median"]
+    from loupiote_amd import _abi as lp_abi
+    lib_options = {name: int(r.get_option(name)) for name in sorted(lp_abi.OPTIONS)}   # what the library chose / was told: the line says which pipeline it timed
     r.close()
 
     # ================================================================== strong scaling of ONE frame, emulated: rank 0's 1/N tile shard on this GPU
@@ -850,7 +852,8 @@ def run(args):
                        "raytrace_calls_per_frame": (sub1[0] - sub0[0]) / max(args.steps * FPS, 1), "wavefronts_per_frame": (sub1[1] - sub0[1]) / max(args.steps * FPS, 1),
                        "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
-                       "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum},
+                       "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum,
+                       "library_options": lib_options},
             "ms_per_frame": elapsed / n_frames * 1e3,
             "frame_ms_percentiles": {"min": frame_ms[0], "p10": frame_ms[len(frame_ms) // 10], "median": frame_ms[len(frame_ms) // 2],
                                      "p90": frame_ms[(9 * len(frame_ms)) // 10], "max": frame_ms[-1], "index_of_max": slowest_frame,
