@@ -382,6 +382,41 @@ def synthetic_hall(seed=3, gravel=12000, needles=160, stack=40, telescope=90):
             "probe": sky_probe(256, 128), "triangles": total, "camera": {"origin": (6.5, 2.2, -6.5), "direction": (-0.75, -0.12, 0.7)}}
 
 
+def origin_dust(seed=4, n=3000):
+    """SPEC §7's margin as a scene: `n` millimetre-sized triangles around the WORLD ORIGIN of a scene 2 000 units across (two far triangles set the extent).  The Woop test's
+    rounding grows with the ray's coordinates, a triangle's padding with the triangle's own: rays from far away that graze these triangles are where a tree would lose a hit."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.05, 0.05, (n, 1, 3)).astype(np.float32)
+    tiny = (c + rng.normal(0, 1e-3, (n, 3, 3))).astype(np.float32)
+    far = np.array([[[-1000, -1000, -1000], [-999, -1000, -1000], [-1000, -999, -1000]], [[1000, 1000, 1000], [999, 1000, 1000], [1000, 999, 1000]]], np.float32)
+    tris = np.concatenate([tiny, far])
+    mesh = _mesh(tris.reshape(-1, 3), np.arange(tris.shape[0] * 3, dtype=np.uint32))
+    light = np.zeros(1, dtype=[("normal", "<f4", 4), ("tangent", "<f4", 4), ("bitangent", "<f4", 4), ("origin", "<f4", 4)])
+    light["normal"] = (0, -1, 0, 0)
+    light["tangent"] = (1, 0, 0, 1.0)
+    light["bitangent"] = (0, 0, 1, 1.0)
+    light["origin"] = (0.0, 500.0, 0.0, 10.0)
+    return {"name": "origin_dust(seed=%d)" % seed, "meshes": [mesh], "instances": [(1, _translate(0, 0, 0), 1)], "materials": [((0.8, 0.8, 0.8, 1), 0.5, 0.0, INVALID, INVALID)],
+            "images": [], "lights": [light], "probe": sky_probe(64, 32), "triangles": int(tris.shape[0]), "camera": {"origin": (0.0, 0.0, 3.0), "direction": (0.0, 0.0, -1.0)},
+            "dust": tiny}
+
+
+def grazing_rays(dust, m, seed=5, extent=1000.0):
+    """`m` rays towards vertices (half of them) and random points (many near an edge) of random triangles of `dust` (k, 3, 3), a third from nearby, the rest from up to
+    `extent` away; returns origins, unit directions and the distance to the point aimed at"""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-extent, extent, (m, 3)).astype(np.float32)
+    o[: m // 3] = rng.uniform(-2, 2, (m // 3, 3)).astype(np.float32)
+    t = rng.integers(0, dust.shape[0], m)
+    w = rng.dirichlet((0.6, 0.6, 0.6), m).astype(np.float32)
+    w[: m // 2] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, m // 2)]
+    target = (dust[t] * w[:, :, None]).sum(axis=1).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    dist = np.linalg.norm(d, axis=1).astype(np.float32)
+    d /= dist[:, None]
+    return o, d.astype(np.float32), dist
+
+
 def to_product(desc):
     """feed a description through the C ABI; returns loupiote_amd.Scene"""
     from . import api

@@ -151,6 +151,7 @@ struct orc_scene {
     /* private acceleration structure: binned-SAH BVH2 over triangle centroids (median split as the fall-back);
        hits do not depend on it (SPEC §7), only the oracle's speed does */
     bnode *nodes; uint32_t n_nodes; uint32_t *order;
+    float max_abs;         /* the largest |coordinate| of any vertex: the scale the Woop test's rounding follows for rays that start anywhere in the scene */
 };
 
 /* SPEC §6: world->unit-triangle affine map, computed in double, rounded once */
@@ -204,8 +205,10 @@ static void tri_bounds(const orc_scene *s, uint32_t tri, float lo[3], float hi[3
      * (a floor at y = 0 got no padding from a per-axis rule; round 3: one wrong pixel-sample in 5.3e8 at 3840x2160x64) */
     float m = 0.0f;
     for (int a = 0; a < 3; ++a) m = fmax2(m, fmax2(fabsf(lo[a]), fabsf(hi[a])));
+    /* round 5: ... and with the RAY's position, which may be anywhere in the scene: tiny triangles around the origin of a 2 000-unit scene lost 1 grazing hit in
+     * 60 000 to the tree (brute force and the product's tree found it; profiles/r05_experiments_ab.txt U).  2e-6 of the scene's largest coordinate on top */
     for (int a = 0; a < 3; ++a) {
-        float e = 1e-5f * m + 1e-6f * (hi[a] - lo[a]) + 1e-20f;
+        float e = 1e-5f * m + 2e-6f * s->max_abs + 1e-6f * (hi[a] - lo[a]) + 1e-20f;
         lo[a] -= e; hi[a] += e;
     }
 }
@@ -347,6 +350,9 @@ orc_scene *orc_scene_create(uint32_t n_tris, const orc_vertex *tri_verts, const 
         float *cent = (float *)malloc(sizeof(float) * 3 * (size_t)n_tris);
         float *tlo = (float *)malloc(sizeof(float) * 3 * (size_t)n_tris);
         float *thi = (float *)malloc(sizeof(float) * 3 * (size_t)n_tris);
+        s->max_abs = 0.0f;
+        for (size_t i = 0; i < 3 * (size_t)n_tris; ++i)
+            for (int a = 0; a < 3; ++a) s->max_abs = fmax2(s->max_abs, fabsf(s->verts[i].position[a]));
         for (uint32_t t = 0; t < n_tris; ++t) {
             tri_bounds(s, t, tlo + 3 * (size_t)t, thi + 3 * (size_t)t);
             for (int a = 0; a < 3; ++a) cent[3 * (size_t)t + a] = 0.5f * (tlo[3 * (size_t)t + a] + thi[3 * (size_t)t + a]);

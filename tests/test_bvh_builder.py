@@ -122,14 +122,14 @@ def test_mixed_scale_hall_matches_brute_force(bvh_check, tmp_path):
 
 
 def test_grazing_rays_at_a_scale_ratio_of_a_million_lose_no_hit(bvh_check, tmp_path):
-    """the margin of SPEC §7 in numbers: 3 000 millimetre-sized triangles around the world origin in a scene 2 000 units across (two far triangles set the extent) —
-    a quarter of the rays is aimed at vertices and edge points of random triangles from up to a thousand units away, where the Woop test's rounding (which grows
-    with the ray's coordinates) is largest against the triangle padding (which grows with the triangle's): every closest hit is the brute-force one.
+    """the margin of SPEC §7 in numbers (scenes.origin_dust): 3 000 millimetre-sized triangles around the world origin in a scene 2 000 units across (two far triangles
+    set the extent) — a quarter of the walker's rays is aimed at vertices and edge points of random triangles from up to a thousand units away, where the Woop test's rounding
+    (which grows with the ray's coordinates) is largest against the triangle padding (which grows with the triangle's): every closest hit is the brute-force one.
     (At a ratio of 10^12 — a chain of triangles at x = 2^(0.08 k) — the same walker loses 5 of 5 000 such hits: SPEC §7 states the domain.)"""
-    rng = np.random.default_rng(4)
-    n = 3000
-    c = rng.uniform(-0.05, 0.05, (n, 1, 3)).astype(np.float32)
-    tiny = (c + rng.normal(0, 1e-3, (n, 3, 3))).astype(np.float32)
-    far = np.array([[[-1000, -1000, -1000], [-999, -1000, -1000], [-1000, -999, -1000]], [[1000, 1000, 1000], [999, 1000, 1000], [1000, 999, 1000]]], np.float32)
-    out = run(bvh_check, tmp_path, np.concatenate([tiny, far]), 150000)
-    assert out["triangles"] == n + 2 and out["mismatches"] == 0 and out["bad_refs"] == 0 and out["hits"] > 10000, out
+    import sys
+    sys.path.insert(0, ROOT)
+    from loupiote_amd import scenes
+    d = scenes.origin_dust()
+    tris = np.concatenate([m["positions"][m["indices"]].reshape(-1, 9) for m in d["meshes"]])
+    out = run(bvh_check, tmp_path, tris, 150000)
+    assert out["triangles"] == 3002 and out["mismatches"] == 0 and out["bad_refs"] == 0 and out["hits"] > 10000, out

@@ -85,30 +85,12 @@ def test_hall_rays_from_inside_the_gravel_and_along_the_slivers(device, hall):
 
 
 def test_grazing_rays_at_a_scale_ratio_of_a_million_match_brute_force(device):
-    """SPEC §7's margin on the GPU: 3 000 millimetre-sized triangles around the world origin in a scene 2 000 units across; rays from up to a thousand units away aimed at
-    vertices and edge points of random triangles (where a box test that is not conservative against the Woop test's rounding would lose the hit), and random ones:
+    """SPEC §7's margin on the GPU (scenes.origin_dust): 3 000 millimetre-sized triangles around the world origin in a scene 2 000 units across; rays from up to a thousand
+    units away aimed at vertices and edge points of random triangles (where a box test that is not conservative against the Woop test's rounding would lose the hit):
     lpt_trace_closest / lpt_trace_occluded equal the oracle's BRUTE FORCE bit for bit (the CPU twin of this test walks the same tree: tests/test_bvh_builder.py)"""
     from oracle import orc
-    rng = np.random.default_rng(4)
-    n = 3000
-    c = rng.uniform(-0.05, 0.05, (n, 1, 3)).astype(np.float32)
-    tiny = (c + rng.normal(0, 1e-3, (n, 3, 3))).astype(np.float32)
-    far = np.array([[[-1000, -1000, -1000], [-999, -1000, -1000], [-1000, -999, -1000]], [[1000, 1000, 1000], [999, 1000, 1000], [1000, 999, 1000]]], np.float32)
-    tris = np.concatenate([tiny, far])
-    mesh = scenes._mesh(tris.reshape(-1, 3), np.arange(tris.shape[0] * 3, dtype=np.uint32))
-    light = np.zeros(1, dtype=[("normal", "<f4", 4), ("tangent", "<f4", 4), ("bitangent", "<f4", 4), ("origin", "<f4", 4)])
-    light["normal"] = (0, -1, 0, 0); light["tangent"] = (1, 0, 0, 1.0); light["bitangent"] = (0, 0, 1, 1.0); light["origin"] = (0.0, 500.0, 0.0, 10.0)
-    desc = {"name": "origin_dust", "meshes": [mesh], "instances": [(1, scenes._translate(0, 0, 0), 1)], "materials": [((0.8, 0.8, 0.8, 1), 0.5, 0.0, scenes.INVALID, scenes.INVALID)],
-            "images": [], "lights": [light], "probe": scenes.sky_probe(64, 32), "triangles": tris.shape[0], "camera": {"origin": (0.0, 0.0, 3.0), "direction": (0.0, 0.0, -1.0)}}
-    m = 60000
-    o = rng.uniform(-1000, 1000, (m, 3)).astype(np.float32)
-    o[: m // 3] = rng.uniform(-2, 2, (m // 3, 3)).astype(np.float32)                     # a third from nearby
-    t = rng.integers(0, n, m)
-    w = rng.dirichlet((0.6, 0.6, 0.6), m).astype(np.float32)
-    w[: m // 2] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, m // 2)]                # half at vertices, half at points of the triangle (many on or near an edge)
-    target = (tiny[t] * w[:, :, None]).sum(axis=1).astype(np.float32)
-    d = (target - o).astype(np.float32)
-    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    desc = scenes.origin_dust()
+    o, d, dist = scenes.grazing_rays(desc["dust"], 60000)
     osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
     sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
     got, want = sg.trace_closest(o, d), osc.trace_closest(o, d, brute_force=True)
@@ -116,6 +98,6 @@ def test_grazing_rays_at_a_scale_ratio_of_a_million_match_brute_force(device):
     assert np.array_equal(got["prim"], want["prim"])
     for k in ("t", "u", "v"):
         assert got[k].tobytes() == want[k].tobytes()
-    tmax = (np.linalg.norm(target - o, axis=1) * rng.uniform(0.5, 1.5, m)).astype(np.float32)
+    tmax = (dist * np.random.default_rng(6).uniform(0.5, 1.5, dist.shape[0])).astype(np.float32)
     assert np.array_equal(sg.trace_occluded(o, d, tmax), osc.trace_occluded(o, d, tmax, brute_force=True))
     sg.close()
