@@ -61,10 +61,13 @@ struct Accel {
     std::vector<uint32_t> leaf_prim;     // leaf slot -> baked triangle id
     uint32_t max_depth = 0;
     float build_ms = 0.f;
+    float max_abs = 0.f;                 // the largest |coordinate| of any baked vertex: what the scene-wide part of the triangle padding follows (bvh.cpp padded_box)
     // bookkeeping for refits (lpt_scene_gpu_update_instances)
     std::vector<uint32_t> inst_first, inst_count;  // per scene instance: its run of baked triangles
     std::vector<uint32_t> level_start;             // nodes are stored breadth first: level l = [level_start[l], level_start[l+1])
 };
+
+constexpr float kScenePad = 2e-6f;   // triangle padding per unit of the scene's largest |coordinate| (host builder, LBVH and refit alike)
 
 // bvh.cpp
 int bake_and_build(const lpt_scene &scene, Accel &out);

@@ -116,6 +116,7 @@ static const Rccl *rccl() {
 struct lpt_scene_gpu {
     lpt_device *dev = nullptr;
     DScene d{};
+    float max_abs = 0.f;            // the scene's largest |coordinate|: d.pad_abs = kScenePad x this (host build: Accel::max_abs; GPU build: the bounds pass; refit: the root box)
     void *nodes = nullptr, *woop = nullptr, *leaf_prim = nullptr, *tri_verts = nullptr;
     void *materials = nullptr, *lights = nullptr, *texels = nullptr, *images = nullptr, *srgb_lut = nullptr;
     // paired textures (kernels.h DScene::pair_texels): (albedo image, mra image) -> pair index, for the materials whose two
@@ -352,6 +353,9 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
     }
     float binv[3];
     for (int a = 0; a < 3; ++a) binv[a] = bhi[a] > blo[a] ? 1.0f / (bhi[a] - blo[a]) : 0.0f;
+    sg->max_abs = 0.0f;
+    for (int a = 0; a < 3; ++a) sg->max_abs = std::max(sg->max_abs, std::max(fabsf(blo[a]), fabsf(bhi[a])));
+    sg->d.pad_abs = kScenePad * sg->max_abs;   // the scene-wide part of the triangle padding (bvh.cpp padded_box), for every kernel below that pads a triangle
 
     // scratch: one arena per scene, kept for the next rebuild (about 330 B per triangle); a bump allocator over it
     size_t sort_bytes = 0, scan_bytes = 0;
@@ -744,6 +748,8 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     // a stack entry holds the unvisited siblings below a node at depth 1..max_depth-1 (the root's own group has one
     // member and is never pushed, the deepest nodes have no inner children): max_depth-1 entries are enough
     d.stack_entries = acc.max_depth > 2u ? acc.max_depth - 1u : 1u;
+    sg->max_abs = acc.max_abs;      // 0 on the GPU-build path: build_lbvh sets it from its bounds pass
+    d.pad_abs = kScenePad * acc.max_abs;
     d.woop = (const float4 *)sg->woop;
     d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     d.tri_verts = (const float4 *)sg->tri_verts;
@@ -850,12 +856,24 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         }
     }
     if (changed && sg->stats.triangles) {
-        for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
-            const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
-            if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
+        // the padding's scene-wide part follows the scene's largest coordinate: a scene that GREW under the edit (the root box after the refit says so) is refitted
+        // once more with the larger pad; it never shrinks (a pad a little too wide costs nothing)
+        for (int pass = 0; pass < 2; ++pass) {
+            for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
+                const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
+                if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
+            }
+            HIP_TRY(hipGetLastError());
+            float root[8];
+            HIP_TRY(hipMemcpyAsync(root, sg->node_lo, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(root + 4, sg->node_hi, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            float now_abs = 0.0f;
+            for (int a = 0; a < 3; ++a) now_abs = std::max(now_abs, std::max(fabsf(root[a]), fabsf(root[4 + a])));
+            if (!(now_abs > 1.25f * sg->max_abs)) break;
+            sg->max_abs = now_abs;
+            sg->d.pad_abs = kScenePad * now_abs;   // (renderers read sg->d at submission)
         }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(s));
     }
     if (out_rebaked) *out_rebaked = changed;
     return LPT_OK;

@@ -53,6 +53,7 @@ struct DScene {
     const uint2 *pair_texels;
     const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row (ceil(width / 3))
     uint32_t n_tris, n_materials, n_lights, n_images, n_pairs;
+    float pad_abs;               // the scene-wide part of the triangle padding (refit / LBVH; bvh.cpp padded_box): kScenePad x the scene's largest |coordinate|
 };
 constexpr uint32_t kPairedBit = 0x40000000u;
 
@@ -2282,7 +2283,7 @@ __device__ __forceinline__ void refit_grow_tri(const DScene &sc, uint32_t prim, 
     for (int a = 0; a < 3; ++a) {
         float l = fminf(fminf(pp[a][0], pp[a][1]), pp[a][2]), h = fmaxf(fmaxf(pp[a][0], pp[a][1]), pp[a][2]);
         const float m = fmaxf(fabsf(l), fabsf(h));
-        const float e = 4e-6f * m + 1e-6f * (h - l) + 1e-30f;   // bvh.cpp padded_box
+        const float e = 4e-6f * m + sc.pad_abs + 1e-6f * (h - l) + 1e-30f;   // bvh.cpp padded_box
         l -= e; h += e;
         lo[a] = fminf(lo[a], l); hi[a] = fmaxf(hi[a], h);
     }

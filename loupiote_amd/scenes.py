@@ -386,8 +386,15 @@ def origin_dust(seed=4, n=3000):
     """SPEC §7's margin as a scene: `n` millimetre-sized triangles around the WORLD ORIGIN of a scene 2 000 units across (two far triangles set the extent).  The Woop test's
     rounding grows with the ray's coordinates, a triangle's padding with the triangle's own: rays from far away that graze these triangles are where a tree would lose a hit."""
     rng = np.random.default_rng(seed)
-    c = rng.uniform(-0.05, 0.05, (n, 1, 3)).astype(np.float32)
-    tiny = (c + rng.normal(0, 1e-3, (n, 3, 3))).astype(np.float32)
+    tiny = np.zeros((0, 3, 3), np.float32)
+    while tiny.shape[0] < n:   # well-shaped triangles only: the Woop map of a sliver (three nearly collinear vertices) is ill-conditioned, and from a million triangle sizes
+        # away its rounding accepts rays that pass several triangle LENGTHS beyond the sliver's tip — no box padding is a margin for that (profiles/r05_experiments_ab.txt U)
+        c = rng.uniform(-0.05, 0.05, (n, 1, 3)).astype(np.float32)
+        t = (c + rng.normal(0, 1e-3, (n, 3, 3))).astype(np.float32)
+        e = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 0] - t[:, 2]], axis=1).astype(np.float64)
+        longest = np.linalg.norm(e, axis=2).max(axis=1)
+        area2 = np.linalg.norm(np.cross(e[:, 0], -e[:, 2]), axis=1)
+        tiny = np.concatenate([tiny, t[area2 / longest >= 0.35 * longest]])[:n]      # altitude over the longest edge >= 0.35 of it
     far = np.array([[[-1000, -1000, -1000], [-999, -1000, -1000], [-1000, -999, -1000]], [[1000, 1000, 1000], [999, 1000, 1000], [1000, 999, 1000]]], np.float32)
     tris = np.concatenate([tiny, far])
     mesh = _mesh(tris.reshape(-1, 3), np.arange(tris.shape[0] * 3, dtype=np.uint32))

@@ -8,7 +8,7 @@ import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
 from oracle import harness
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the arms of tests/conftest.py PIPELINES
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +42,7 @@ def _render(device, desc, size, depth, frames, options=None, shard=None):
     return img, (c.closest, c.shadow, c.shaded)
 
 
+@pytest.mark.usefixtures("pipeline")   # over the arms of tests/conftest.py PIPELINES
 @pytest.mark.parametrize("size,depth,frames", [((160, 90), 6, 2), ((384, 216), 8, 1)])
 def test_hall_frames_equal_the_oracle(device, hall, size, depth, frames):
     from oracle import orc
@@ -53,6 +54,7 @@ def test_hall_frames_equal_the_oracle(device, hall, size, depth, frames):
     assert img.tobytes() == orc.resolve(acc).tobytes()
 
 
+@pytest.mark.usefixtures("pipeline")
 def test_hall_shards_add_up_to_the_whole_frame(device, hall):
     desc, _ = hall
     whole, counts = _render(device, desc, (320, 184), 6, 2)
@@ -90,14 +92,16 @@ def test_grazing_rays_at_a_scale_ratio_of_a_million_match_brute_force(device):
     lpt_trace_closest / lpt_trace_occluded equal the oracle's BRUTE FORCE bit for bit (the CPU twin of this test walks the same tree: tests/test_bvh_builder.py)"""
     from oracle import orc
     desc = scenes.origin_dust()
-    o, d, dist = scenes.grazing_rays(desc["dust"], 60000)
     osc = orc.OracleScene.from_scene(harness.to_oracle(desc), probe=desc["probe"])
-    sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
-    got, want = sg.trace_closest(o, d), osc.trace_closest(o, d, brute_force=True)
-    assert (want["prim"] != 0xFFFFFFFF).mean() > 0.3
-    assert np.array_equal(got["prim"], want["prim"])
-    for k in ("t", "u", "v"):
-        assert got[k].tobytes() == want[k].tobytes()
-    tmax = (dist * np.random.default_rng(6).uniform(0.5, 1.5, dist.shape[0])).astype(np.float32)
-    assert np.array_equal(sg.trace_occluded(o, d, tmax), osc.trace_occluded(o, d, tmax, brute_force=True))
-    sg.close()
+    for gpu_build in (False, True):          # the host builder's tree and the GPU builder's (LBVH + refit: the same padding rule on the device)
+        sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device, gpu_build=gpu_build)
+        for seed in (5, 6):
+            o, d, dist = scenes.grazing_rays(desc["dust"], 100000, seed=seed)
+            got, want = sg.trace_closest(o, d), osc.trace_closest(o, d, brute_force=True)
+            assert (want["prim"] != 0xFFFFFFFF).mean() > 0.3
+            assert np.array_equal(got["prim"], want["prim"]), (gpu_build, seed, int((got["prim"] != want["prim"]).sum()))
+            for k in ("t", "u", "v"):
+                assert got[k].tobytes() == want[k].tobytes()
+            tmax = (dist * np.random.default_rng(6).uniform(0.5, 1.5, dist.shape[0])).astype(np.float32)
+            assert np.array_equal(sg.trace_occluded(o, d, tmax), osc.trace_occluded(o, d, tmax, brute_force=True))
+        sg.close()
