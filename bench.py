@@ -80,9 +80,9 @@ def parse_args(argv=None):
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
     ap.add_argument("--root-weight", type=int, default=0, help="N>1: tile-ownership weight of rank 0 against 8 for every other rank (lpt_renderer_set_shard_weighted): "
                     "rank 0 also unpacks, resolves and reads back the frame, so it gets fewer tiles; 0 = calibrate in the warm-up, 8 = equal shares")
-    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: path_rays, "
-                    "path_waves_per_cu, path_refill, pipe_rays, packet_primary, merge_trace, refill, trace_waves_per_cu, shade_blocks_per_cu, wavefront_rays); every value gives the same frame")
-    ap.add_argument("--sort", type=int, default=0, help="experiments: lpt_renderer_set_sort_queues(flag) on every renderer (1 | 2: outgoing queues by octant, 4: the shading input regrouped in-block)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: the five lpt_option values and the "
+                    "LPT_OPT_EXPERIMENT knobs, by name: path_rays, coop_rays, tail_lanes, packet_primary, wavefront_rays; pipe_rays, refill, trace_waves_per_cu, ...); every value gives the same frame")
+    ap.add_argument("--sort", type=int, default=0, help="experiments: lpt_renderer_set_sort_queues(flag) on every renderer (1 | 2: outgoing queues by octant)")
     ap.add_argument("--no-shard-emulation", action="store_true", help="skip the shard_emulation leg (rank 0's 1/2, 1/4, 1/8 tile shard of the frame on this GPU)")
     ap.add_argument("--blit-mode", choices=["pathtrace", "temporal", "denoised"], default="pathtrace",
                     help="BlitMode of every renderer (renderer.rs:160-167).  temporal / denoised: every raytrace() is a frame of the ASVGF pipeline (BASELINE config 5's form) — "
@@ -277,7 +277,7 @@ def kernel_source_hash():
     """sha256 (16 hex digits) over the device code: what profiles/limits.json and traffic.json record of the tree they were measured on (tools/limits_from_pmc.py)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.h", "pool_kernels.h", "device_math.h"):
+    for f in ("kernels.h", "device_math.h"):
         try:
             h.update(open(os.path.join(ROOT, "loupiote_amd", "csrc", f), "rb").read())
         except OSError:

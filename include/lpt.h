@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LPT_ABI_VERSION 5u
+#define LPT_ABI_VERSION 6u
 
 /* replaces: albedo_rtx::uniforms::INVALID_INDEX (crates/lib/src/loaders/gltf.rs:120,124) */
 #define LPT_INVALID_INDEX 0xFFFFFFFFu
@@ -149,12 +149,15 @@ typedef struct lpt_ray_counts {
     uint64_t packet_nodes; /* nodes entered, once per PACKET (stats enabled only)              */
     uint64_t packet_tris;  /* triangles fetched, once per PACKET (stats enabled only)          */
     /* ABI 5, stats enabled only, per-bounce launches only: the shadow rays that found an occluder, and the occluder-cache PROBE — what a
-     * table of the last occluding triangle per cell of a grid over the shadow rays' origins (LPT_OPT_OCC_CELL_MILLI) would have answered
+     * table of the last occluding triangle per cell of a grid over the shadow rays' origins (LPT_EXP_OCC_CELL_MILLI) would have answered
      * at each ray's start: entries found, and entries whose triangle occludes the ray (a hit would end that ray after one triangle test).
      * A measurement; no kernel uses such a cache. */
     uint64_t shadow_occluded;
     uint64_t occluder_cache_found;
     uint64_t occluder_cache_hits;
+    /* ABI 6: rays of the per-bounce traversal launches that a WHOLE WAVE finished: handed over by the step budget (k_trace_coop re-traces them) or finished in
+     * place at the tail of a launch (LPT_OPT_TAIL_LANES).  Which rays these are depends on scheduling; the frame does not.  Lets a test see that the path ran. */
+    uint64_t wave_rays;
 } lpt_ray_counts;
 
 typedef struct lpt_timing {
@@ -536,61 +539,50 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes);
  * full pixel grid unsorted, renderer.rs:484-509).  flag != 0: the shading pass writes the next-bounce and the shadow-ray
  * queue ordered by direction octant inside every 256-ray block (ballot + popcount per key, LDS prefix sum, still one
  * atomic per block), so a traversal wave's 64 rays share one or two octants.  Results are keyed by pixel slot and do
- * not change by a bit; only traversal coherence does.  flag bits: 1 = next-bounce queue, 2 = shadow queue, 4 = the shading
- * pass's INPUT: the 256 hits of a block are dealt to its threads by kind (surface / emitter / miss), so that a wave runs one
- * branch of the shading code with all its lanes (an in-block regroup: LDS only, no extra global traffic); any other non-zero
+ * not change by a bit; only traversal coherence does.  flag bits: 1 = next-bounce queue, 2 = shadow queue; any other non-zero
  * value = both queues.  Default: off (each measured slower or neutral on the bench scene). */
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag);
-/* new (no reference knob; SURVEY §5 "Config / flags: no"): launch tuning for experiments and for the tests that compare the kernel
- * variants.  EVERY value gives the same frame bit for bit — only which kernels run, and the size of their grids, changes.  The
- * library reads no environment variable for any of this (round 3 did; a host's environment must not change which kernels run). */
+/* new (the reference has three settings, crates/standalone/src/settings.rs:3-17, none of them about launches): what a host may sanely
+ * set about HOW a frame is launched.  EVERY value gives the same frame bit for bit — only which kernels run, and the size of their
+ * grids, changes.  The library reads no environment variable for any of this (a host's environment must not change which kernels run). */
 typedef enum lpt_option {
-    LPT_OPT_MERGE_TRACE = 1,        /* 1 (default): closest-hit rays of bounce b+1 and shadow rays of bounce b in one launch; 0: separate launches */
-    LPT_OPT_PACKET_PRIMARY = 2,     /* bounce 0 by packet traversal, one tree walk per 8x8-pixel patch: 2 (default) = where the patch is narrow (up to 1.8 mrad
+    LPT_OPT_PACKET_PRIMARY = 1,     /* bounce 0 by packet traversal, one tree walk per 8x8-pixel patch: 2 (default) = where the patch is narrow (up to 1.8 mrad
                                      * per pixel: 1080p, 4K, 1024^2 at 45 degrees; not a 270p preview), 1 = always, 0 = never (per ray) */
-    LPT_OPT_PIPE_RAYS = 3,          /* wavefronts of at most this many rays trace with the one-round-trip step (default: all); 0: never */
-    LPT_OPT_WAVEFRONT_RAYS = 4,     /* rays per wavefront an automatic submission aims at (default 4 194 304) */
-    LPT_OPT_REFILL = 5,             /* per-bounce traversal: lanes live below which a wave refills (default 44) */
-    LPT_OPT_TRACE_WAVES_PER_CU = 6, /* per-bounce traversal: persistent waves per CU; 0 (default): sized from the ray count */
-    LPT_OPT_SHADE_BLOCKS_PER_CU = 7,/* shading pass: blocks per CU (default 4) */
-    LPT_OPT_PATH_RAYS = 8,          /* wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (the
+    LPT_OPT_WAVEFRONT_RAYS = 2,     /* rays per wavefront an automatic submission aims at (default 4 194 304) */
+    LPT_OPT_PATH_RAYS = 3,          /* wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (the
                                      * path kernel: no chip-wide barrier per bounce — small frames and the tile shards of a wide multi-GPU
                                      * frame); larger ones take the per-bounce launches of renderer.rs:484-509.  Default 120 000, the
-                                     * measured cross-over (450 000 before the tails of those launches were finished in place); 0: never */
-    LPT_OPT_PATH_WAVES_PER_CU = 9,  /* path kernel: persistent waves per CU (default 16) */
-    LPT_OPT_PATH_REFILL = 10,       /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
-    LPT_OPT_OCC_CELL_MILLI = 11,    /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
-    LPT_OPT_STEP_BUDGET = 12,       /* per-bounce traversal launches: a ray not finished after this many steps is dropped by the per-lane kernel and traced
-                                     * again by a whole wave (k_trace_coop: eight lanes per node), so that the one ray in 10^5 that needs hundreds of steps
-                                     * does not set the duration of the launch; default 48, 0 = off.  Not applied while lpt_renderer_enable_stats is on, and only where
-                                     * LPT_OPT_TAIL_LANES is 0 (the tail finished in place, the default, leaves nothing to drop) */
-    LPT_OPT_BUDGET_RAYS = 13,       /* ... for submissions that leave as ONE wavefront of at most this many rays (default 3 000 000; a larger
-                                     * value applies the budget to every wavefront up to it) */
-    LPT_OPT_PACKET_QUADS = 14,      /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
-                                     * (dense tiles, a multiple of four samples); 0 = always one sample of an 8x8-pixel patch */
-    LPT_OPT_POOL_RAYS = 15,         /* wavefronts of more than LPT_OPT_PATH_RAYS and at most this many rays run every bounce behind the primary hits in ONE
-                                     * launch as a CU-local POOL of trace and shade work (k_pool, round 5): a path is a record that the waves of a block
-                                     * hand to each other through rings in LDS — any wave's idle lanes take the next ray to trace, a wave without rays in
-                                     * flight shades 64 hits of one kind with all its lanes; no chip-wide barrier per bounce (renderer.rs:484-509) and no
-                                     * lane that waits for its own wave's shading batch.  0 (default): never — bit-identical but measured slower than the per-bounce
-                                     * launches at every size (every wave carries the shading body's registers).  A tree so deep that the block's traversal stacks
-                                     * and rings exceed the CU's 160 KB of LDS takes the per-bounce launches whatever this says */
-    LPT_OPT_POOL_SHADERS = 16,      /* pool kernel: waves of a block that prefer shading to tracing (default 2) */
-    LPT_OPT_POOL_ENTRIES = 17,      /* pool kernel: path records per block, 0 (default: 256 per wave of a block) or a power of two in 256..32768 */
-    LPT_OPT_POOL_WAVES = 18,        /* pool kernel: waves per block, 4 / 8 / 16 (default 8: two blocks per CU) */
-    LPT_OPT_POOL_REFILL = 19,       /* pool kernel: lanes tracing at or below which a wave retires its finished rays and refills (default 44) */
-    LPT_OPT_SPLIT_RAYS = 20,        /* a batch above this many rays that would still fit one wavefront leaves as two, on the renderer's lanes (default
-                                     * 3 000 000; 0: never split below LPT_OPT_WAVEFRONT_RAYS) */
-    LPT_OPT_BUDGET_SPLIT = 21,      /* 1: the step budget also applies to the pieces of a cut batch (default 0: only to submissions that leave as one wavefront) */
-    LPT_OPT_TAIL_LANES = 22,        /* the same launches' tails finished IN PLACE: a wave of the per-lane kernel whose queues are dry and that is down to this
-                                     * many live rays (1..8) finishes them cooperatively, all 64 lanes per ray, from where each stands — nothing is
-                                     * dropped, restarted at the root or launched behind.  Default 4; 0 = off, and LPT_OPT_STEP_BUDGET applies instead.  Like the budget, not used while
-                                     * lpt_renderer_enable_stats is on */
-    LPT_OPT_COOP_RAYS = 23          /* wavefronts of at most this many rays — fewer than the chip has wave slots — take the per-bounce launches with EVERY ray
+                                     * measured cross-over; 0: never */
+    LPT_OPT_COOP_RAYS = 4,          /* wavefronts of at most this many rays — fewer than the chip has wave slots — take the per-bounce launches with EVERY ray
                                      * traced by a whole wave (eight lanes per node): the frame of a tiny wavefront is a chain of dependent traversal steps,
                                      * and a wave per ray shortens it several times over (64x36 pixels, 4 spp: 0.72 -> 0.39 ms per frame).  Default 32 000, the measured cross-over;
                                      * 0 = never.  Not used while lpt_renderer_enable_stats is on */
+    LPT_OPT_TAIL_LANES = 5,         /* the tails of the per-bounce traversal launches finished IN PLACE: a wave whose queues are dry and that is down to this
+                                     * many live rays (1..8) finishes them cooperatively, all 64 lanes per ray, from where each stands — nothing is
+                                     * dropped, restarted at the root or launched behind.  Default 4; 0 = off (then LPT_EXP_STEP_BUDGET applies).  For submissions that
+                                     * leave as ONE wavefront; not used while lpt_renderer_enable_stats is on */
+    LPT_OPT_EXPERIMENT_BASE = 256   /* LPT_OPT_EXPERIMENT(name): the tuning knobs of the A/B tools and the variant tests — NOT a stable surface */
 } lpt_option;
+#define LPT_OPT_EXPERIMENT(name) (LPT_OPT_EXPERIMENT_BASE + (name))
+/* The experiment knobs (tools/dev, bench.py --opt, tests that compare kernel variants).  Numbers and meanings may change with any build. */
+typedef enum lpt_experiment {
+    LPT_EXP_PIPE_RAYS = 0,          /* wavefronts of at most this many rays trace with the one-round-trip step (default: all); 0: never */
+    LPT_EXP_REFILL = 1,             /* per-bounce traversal: lanes live below which a wave refills (default 44) */
+    LPT_EXP_TRACE_WAVES_PER_CU = 2, /* per-bounce traversal: persistent waves per CU; 0 (default): sized from the ray count */
+    LPT_EXP_SHADE_BLOCKS_PER_CU = 3,/* shading pass: blocks per CU (default 4) */
+    LPT_EXP_PATH_WAVES_PER_CU = 4,  /* path kernel: persistent waves per CU (default 16) */
+    LPT_EXP_PATH_REFILL = 5,        /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
+    LPT_EXP_OCC_CELL_MILLI = 6,     /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */
+    LPT_EXP_STEP_BUDGET = 7,        /* per-bounce traversal launches with LPT_OPT_TAIL_LANES 0: a ray not finished after this many steps is dropped by the per-lane
+                                     * kernel and traced again by a whole wave (k_trace_coop); default 48, 0 = off.  Not applied while lpt_renderer_enable_stats is on */
+    LPT_EXP_BUDGET_RAYS = 8,        /* the tail in place / the step budget apply to submissions that leave as ONE wavefront of at most this many rays (default 3 000 000) */
+    LPT_EXP_PACKET_QUADS = 9,       /* packet traversal of bounce 0: 1 (default) = a packet is the four samples of a 4x4-pixel quarter where the frame allows it
+                                     * (dense tiles, a multiple of four samples); 0 = always one sample of an 8x8-pixel patch */
+    LPT_EXP_SPLIT_RAYS = 10,        /* a batch above this many rays that would still fit one wavefront leaves as two, on the renderer's lanes (default
+                                     * 3 000 000; 0: never split below LPT_OPT_WAVEFRONT_RAYS) */
+    LPT_EXP_BUDGET_SPLIT = 11       /* 1: the tail in place / the step budget also apply to the pieces of a cut batch (default 0: only to submissions that leave
+                                     * as one wavefront — LPT_EXP_BUDGET_RAYS alone does not turn them on for the pieces) */
+} lpt_experiment;
 int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value);
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value);
 /* The shard layout lpt_renderer_set_shard / lpt_renderer_exchange use, for hosts that run their own exchange (pure host
@@ -609,7 +601,7 @@ int lpt_renderer_get_queue_counts(lpt_renderer *r, uint32_t *closest, uint32_t *
 int lpt_renderer_reset_ray_counts(lpt_renderer *r);
 /* new, stats enabled only: traversal steps per ray over the per-bounce traversal launches of the LAST wavefront — the maximum (the longest
  * ray of a launch sets its duration, docs/ROUNDS.md §5.5) and a histogram by power of two (hist12[k]: 2^k <= steps < 2^(k+1)).  Blocking.
- * The stats kernels run WITHOUT the step budget (LPT_OPT_STEP_BUDGET): every ray is traced to its end by the per-lane kernel, so the histogram, the
+ * The stats kernels run WITHOUT the step budget (LPT_EXP_STEP_BUDGET): every ray is traced to its end by the per-lane kernel, so the histogram, the
  * maximum and the nodes / triangles per ray are those of complete traversals, whatever the option says. */
 int lpt_renderer_get_step_histogram(lpt_renderer *r, uint32_t *max_steps, uint32_t *hist12);
 /* count BVH nodes visited / triangles tested per ray (slower kernel variant) */

@@ -19,10 +19,13 @@ LPT_ERR_HIP = 4
 LPT_ERR_RCCL = 5
 LPT_ERR_INVALID_ARG = 6
 COMM_ID_BYTES = 128
-# lpt_option (include/lpt.h): launch tuning behind lpt_renderer_set_option; every value gives the same frame
-OPTIONS = {"merge_trace": 1, "packet_primary": 2, "pipe_rays": 3, "wavefront_rays": 4, "refill": 5, "trace_waves_per_cu": 6,
-           "shade_blocks_per_cu": 7, "path_rays": 8, "path_waves_per_cu": 9, "path_refill": 10, "occ_cell_milli": 11, "step_budget": 12, "budget_rays": 13, "packet_quads": 14,
-           "pool_rays": 15, "pool_shaders": 16, "pool_entries": 17, "pool_waves": 18, "pool_refill": 19, "split_rays": 20, "budget_split": 21, "tail_lanes": 22, "coop_rays": 23}
+# lpt_option / lpt_experiment (include/lpt.h): launch tuning behind lpt_renderer_set_option; every value gives the same frame.  The five options a host may
+# sanely set, then the experiment knobs (LPT_OPT_EXPERIMENT(name) = 256 + name: A/B tools and variant tests, not a stable surface)
+OPT_EXPERIMENT_BASE = 256
+OPTIONS = {"packet_primary": 1, "wavefront_rays": 2, "path_rays": 3, "coop_rays": 4, "tail_lanes": 5}
+EXPERIMENTS = {"pipe_rays": 0, "refill": 1, "trace_waves_per_cu": 2, "shade_blocks_per_cu": 3, "path_waves_per_cu": 4, "path_refill": 5, "occ_cell_milli": 6,
+               "step_budget": 7, "budget_rays": 8, "packet_quads": 9, "split_rays": 10, "budget_split": 11}
+OPTIONS.update({k: OPT_EXPERIMENT_BASE + v for k, v in EXPERIMENTS.items()})
 EXCHANGE_GATHER_TILES = 0
 HOST_FRAME_HOST_ONLY = 1
 EXCHANGE_REDUCE = 1
@@ -54,7 +57,7 @@ class AccelStats(C.Structure):
 class RayCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("closest", "shadow", "shaded", "nodes", "tris", "shadow_nodes", "shadow_tris",
                                              "wave_steps", "live_lanes", "node_lanes", "tri_lanes", "primary", "packet_nodes", "packet_tris",
-                                             "shadow_occluded", "occluder_cache_found", "occluder_cache_hits")]
+                                             "shadow_occluded", "occluder_cache_found", "occluder_cache_hits", "wave_rays")]
 
 
 class Timing(C.Structure):

@@ -491,8 +491,8 @@ class Renderer:
         _check(A.lib().lpt_renderer_set_sort_queues(self._h, int(flag)))
 
     def set_option(self, name, value):
-        """launch tuning (`_abi.OPTIONS`: merge_trace, packet_primary, pipe_rays, wavefront_rays, refill, trace_waves_per_cu,
-        shade_blocks_per_cu, path_rays, path_waves_per_cu, path_refill); every value gives the same frame bit for bit"""
+        """launch tuning (`_abi.OPTIONS`: the five `lpt_option` values — packet_primary, wavefront_rays, path_rays, coop_rays, tail_lanes — and, by
+        name, the `LPT_OPT_EXPERIMENT` knobs of the A/B tools and variant tests); every value gives the same frame bit for bit"""
         _check(A.lib().lpt_renderer_set_option(self._h, A.OPTIONS[name] if isinstance(name, str) else int(name), int(value)))
 
     def get_option(self, name):

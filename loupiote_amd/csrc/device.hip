@@ -24,7 +24,6 @@
 #include "common.h"
 #include "kernels.h"
 #include "build_kernels.h"
-#include "pool_kernels.h"
 #include <hipcub/hipcub.hpp>
 #include <rccl/rccl.h>
 
@@ -43,7 +42,6 @@ struct lpt_device {
     int compute_units = 0;
     char name[128] = {0};
     std::vector<lpt_renderer *> renderers;   // live renderers of this device: scene / probe edits submit their recorded calls first
-    bool pool_attr_set = false;              // k_pool's dynamic-LDS attribute has been raised on this device (hipFuncSetAttribute is per device)
 };
 
 // one RCCL communicator rank (frame exchange); created by lpt_comm_create
@@ -161,8 +159,6 @@ struct Wavefront {
     ShadowQueue sq{};
     float4 *hits = nullptr, *Lsum = nullptr;
     uint32_t *strag = nullptr;      // the stragglers of a traversal launch (k_trace's step budget -> k_trace_coop): ray index | shadow << 31
-    float4 *pool_slab = nullptr;    // k_pool's path records: blocks x entries x kPoolRec (allocated by the first wavefront that takes the pool kernel)
-    size_t pool_slab_elems = 0;
     FrameCounters *ctr = nullptr;
     size_t ray_cap = 0;             // rays (pixel slots x samples) the per-ray buffers can hold; 0 = not allocated yet
     hipEvent_t done = nullptr;      // recorded on `stream` behind the lane's last traversal / shading launch
@@ -170,17 +166,16 @@ struct Wavefront {
     bool consumed_recorded = false;
 };
 constexpr int kMaxLanes = 4;
-constexpr uint32_t kStepBudget = 48u, kBudgetRays = 3000000u;  // defaults of LPT_OPT_STEP_BUDGET / LPT_OPT_BUDGET_RAYS (measured: profiles/r04_experiments_ab.txt H)
+constexpr uint32_t kStepBudget = 48u, kBudgetRays = 3000000u;  // defaults of LPT_EXP_STEP_BUDGET / LPT_EXP_BUDGET_RAYS (measured: profiles/r04_experiments_ab.txt H)
 constexpr float kPacketMaxPixelRad = 1.8e-3f;    // bounce 0 as packets up to this angle per pixel (measured: 1.53 mrad, 960x540: packets 4.46 against 4.51 ms; 2.05 mrad, 720x405: 3.32 against 3.20)
 constexpr uint32_t kOccEntries = 1u << 18;       // occluder-cache probe: 1 MB, L2-resident
 constexpr uint32_t kPathRays = 120000u;           // rays of a wavefront up to which the path kernel is used: the measured cross-over against the per-bounce launches with their tails in place
                                                   // (whole frames, ms: 113 k rays 0.913 path / 0.932 per bounce, 147 k 1.07 / 0.99, 332 k 1.89 / 1.40; it was 450 000 against the budget pair)
-constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_OPT_SPLIT_RAYS)
+constexpr uint64_t kSplitRays = 3000000ull;       // a batch above this leaves as at least two wavefronts (LPT_EXP_SPLIT_RAYS)
 constexpr uint32_t kCoopRays = 32000u;            // rays of a wavefront up to which EVERY ray is traced by a whole wave (k_trace_coop over the queues): the measured cross-over (28 k rays:
                                                   // 0.755 -> 0.652 ms per frame, 37 k: 0.765 -> 0.787; profiles/r05_experiments_ab.txt V)
 constexpr uint32_t kPacketBlocksPerCu = 128u;   // k_trace_packet's grid: one-wave blocks, packets dealt by stride (32 / 64 per CU: the same, round 5)
 constexpr uint32_t kCoopWavesPerCu = 32u;   // k_trace_coop's grid: a wave per straggler, most waves find none and leave (8 / 4 per CU: the same 2.90 ms per 1/8-shard frame, round 5)
-constexpr uint32_t kPoolRays = 0u;                // rays of a wavefront up to which the pool kernel is used (LPT_OPT_POOL_RAYS; 0 = never)
 constexpr uint64_t kWavefrontRays = 1ull << 22;   // rays (pixel slots x samples) per wavefront an automatic submission aims at
 
 struct lpt_renderer {
@@ -207,7 +202,7 @@ struct lpt_renderer {
     uint32_t max_fused = 0;    // 0 = auto: up to 64 calls wait for the next submission point, which cuts them into wavefronts of about 4 M rays
                                // (spatially: runs of tile rows x all the samples); n >= 1: n calls are ONE wavefront and launch when the n-th is recorded
     uint32_t packet_primary = 2u;  // bounce 0 by packet traversal (k_trace_packet): 2 = where an 8x8-pixel patch is narrow enough (wavefront_trace), 1 = always, 0 = never (LPT_OPT_PACKET_PRIMARY)
-    uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_OPT_PIPE_RAYS 0: none
+    uint32_t pipe_rays = 0x7FFFFFFFu;   // wavefronts of at most this many rays trace with the one-round-trip step (k_trace<.., PIPE>): all of them; LPT_EXP_PIPE_RAYS 0: none
     uint64_t wavefront_rays = kWavefrontRays;   // LPT_OPT_WAVEFRONT_RAYS: tests cut small frames into many wavefronts
     // wavefronts of at most this many rays run every bounce behind the primary hits in ONE launch (k_path: no chip-wide barrier per
     // bounce); larger ones take the per-bounce launches, whose drains are then a few per cent.  LPT_OPT_PATH_RAYS; 0: never
@@ -229,9 +224,8 @@ struct lpt_renderer {
     // traversal tuning (lpt_renderer_set_option, for experiments)
     int refill = 44;
     int sort_queues = 0;       // k_shade emits both ray queues ordered by direction octant within a block (lpt_renderer_set_sort_queues)
-    bool merge_trace = true;
-    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_OPT_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
-    uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_OPT_TRACE_WAVES_PER_CU pins it
+    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_EXP_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
+    uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_EXP_TRACE_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
     float4 *accum = nullptr, *scratch = nullptr;
@@ -247,19 +241,16 @@ struct lpt_renderer {
     // per-bounce traversal launches: a ray that is not finished after this many steps is handed to k_trace_coop (a whole wave per ray); 0 = off.
     // Applies to wavefronts of at most `budget_rays` rays: where a launch's longest ray sets its duration
     uint32_t step_budget = kStepBudget, budget_rays = kBudgetRays;
-    bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_OPT_BUDGET_SPLIT)
+    bool budget_split = false;     // the budget also for the pieces of a cut batch (LPT_EXP_BUDGET_SPLIT)
     // the same launches' tails finished IN PLACE instead (kernels.h tail_park / tail_walk): a wave whose queues are dry and that is down to this many live rays finishes them
     // cooperatively from where they stand (default); 0: off (then the step budget + k_trace_coop pair applies).  LPT_OPT_TAIL_LANES
     uint32_t coop_rays = kCoopRays;   // LPT_OPT_COOP_RAYS
     uint32_t tail_lanes = 4u;      // 1/8 shard of the bench frame: 3, 4, 5 the same (2.74 ms per frame against 2.90 with the budget pair), 2 and 8 slower
-    uint64_t split_rays = kSplitRays;   // LPT_OPT_SPLIT_RAYS
-    // the pool kernel (pool_kernels.h): wavefronts of path_rays < rays <= pool_rays
-    uint32_t pool_rays = kPoolRays, pool_shaders = 2u, pool_entries = 0u, pool_waves = 8u;   // pool_entries 0: 256 records per wave of a block
-    int pool_refill = 44;
+    uint64_t split_rays = kSplitRays;   // LPT_EXP_SPLIT_RAYS
     uint32_t *err_host = nullptr, *err_dev = nullptr;   // the device's error word: one page-locked host word the kernels write (a bounded wait that ran out), checked behind every blocking call
-    bool packet_quads = true;      // a packet of bounce 0 = the four samples of a 4x4-pixel quarter (where the queue order allows it) instead of one sample of an 8x8 patch (LPT_OPT_PACKET_QUADS)
+    bool packet_quads = true;      // a packet of bounce 0 = the four samples of a 4x4-pixel quarter (where the queue order allows it) instead of one sample of an 8x8 patch (LPT_EXP_PACKET_QUADS)
     uint32_t *occ_table = nullptr;   // occluder-cache probe (stats only): kOccEntries leaf slots + 1, zero = empty; allocated by enable_stats
-    float occ_cell = 0.25f;          // its grid cell (scene units); LPT_OPT_OCC_CELL_MILLI
+    float occ_cell = 0.25f;          // its grid cell (scene units); LPT_EXP_OCC_CELL_MILLI
     void *default_probe = nullptr;
     float *srgb_thr = nullptr;   // 256 floats: the linear value at which sRGB code i starts (k_tonemap, SPEC §13.2)
     void *noise = nullptr;
@@ -314,7 +305,7 @@ static int flush_device(lpt_device *dev) {
 }
 // what read_radiance / read_pixels / blit show: the exchanged whole frame after lpt_renderer_exchange, else the local target
 static inline const float4 *presented_target(const lpt_renderer *r) { return (r->presented && r->frame) ? r->frame : r->accum; }
-// The device's error word (a page-locked host word the kernels write when a bounded wait runs out: k_pool's ring locks and idle waits).  Read behind a
+// The device's error word (a page-locked host word the kernels write when a bounded wait runs out; no shipped kernel has one since k_pool left the library in round 6).  Read behind a
 // blocking call, once the stream has been waited for: the frame that raised it is void.
 static int check_device_error(lpt_renderer *r) {
     if (!r->err_host) return LPT_OK;
@@ -1082,9 +1073,6 @@ static void free_ray_buffers(Wavefront &wf) {
     wf.q[0] = Queue{}; wf.q[1] = Queue{}; wf.sq = ShadowQueue{};
     wf.hits = wf.Lsum = nullptr;
     wf.strag = nullptr;
-    if (wf.pool_slab) hipFree(wf.pool_slab);
-    wf.pool_slab = nullptr;
-    wf.pool_slab_elems = 0;
     wf.ray_cap = 0;
 }
 
@@ -1454,8 +1442,8 @@ int lpt_renderer_set_lanes(lpt_renderer *r, int lanes) {
 int lpt_renderer_set_sort_queues(lpt_renderer *r, int flag) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_sort_queues: null");
     FLUSH_OR_RETURN(r);
-    // 1: next-bounce queue, 2: shadow queue, 4: the shading INPUT regrouped by kind inside each block; any other non-zero value: both queues
-    r->sort_queues = flag ? ((flag & 7) ? (flag & 7) : 3) : 0;
+    // 1: next-bounce queue, 2: shadow queue; any other non-zero value: both queues
+    r->sort_queues = flag ? ((flag & 3) ? (flag & 3) : 3) : 0;
     return LPT_OK;
 }
 // Launch tuning that experiments and the variant tests switch (the reference has no counterpart: SURVEY §5 "Config / flags: no").
@@ -1464,27 +1452,21 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     if (!r) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: null");
     FLUSH_OR_RETURN(r);
     switch (option) {
-    case LPT_OPT_MERGE_TRACE: r->merge_trace = value != 0; break;
     case LPT_OPT_PACKET_PRIMARY: if (value > 2u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PACKET_PRIMARY: 0 (never), 1 (always), 2 (by pixel footprint)"); r->packet_primary = (uint32_t)value; break;
-    case LPT_OPT_PIPE_RAYS: r->pipe_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PIPE_RAYS): r->pipe_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_WAVEFRONT_RAYS: r->wavefront_rays = std::max<uint64_t>(value, 64u); break;
-    case LPT_OPT_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_REFILL: 0..63"); r->refill = (int)value; break;
-    case LPT_OPT_TRACE_WAVES_PER_CU: if (value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_TRACE_WAVES_PER_CU: 0 (auto) or 1..32"); r->trace_waves_per_cu = (uint32_t)value; break;
-    case LPT_OPT_SHADE_BLOCKS_PER_CU: if (value < 1u || value > 64u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_SHADE_BLOCKS_PER_CU: 1..64"); r->shade_blocks_per_cu = (uint32_t)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_REFILL): if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_REFILL: 0..63"); r->refill = (int)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_TRACE_WAVES_PER_CU): if (value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_TRACE_WAVES_PER_CU: 0 (auto) or 1..32"); r->trace_waves_per_cu = (uint32_t)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_SHADE_BLOCKS_PER_CU): if (value < 1u || value > 64u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_SHADE_BLOCKS_PER_CU: 1..64"); r->shade_blocks_per_cu = (uint32_t)value; break;
     case LPT_OPT_PATH_RAYS: r->path_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
-    case LPT_OPT_PATH_WAVES_PER_CU: if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
-    case LPT_OPT_PATH_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
-    case LPT_OPT_OCC_CELL_MILLI: r->occ_cell = (float)std::min<uint64_t>(value, 1000000u) * 1.0e-3f; break;
-    case LPT_OPT_STEP_BUDGET: r->step_budget = (uint32_t)std::min<uint64_t>(value, 1u << 20); break;
-    case LPT_OPT_BUDGET_RAYS: r->budget_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
-    case LPT_OPT_PACKET_QUADS: r->packet_quads = value != 0; break;
-    case LPT_OPT_POOL_RAYS: r->pool_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
-    case LPT_OPT_POOL_SHADERS: if (value > 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_SHADERS: 0..16"); r->pool_shaders = (uint32_t)value; break;
-    case LPT_OPT_POOL_ENTRIES: if (value && (value < 256u || value > 32768u || (value & (value - 1u)))) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_ENTRIES: 0 (256 per wave of a block) or a power of two in 256..32768"); r->pool_entries = (uint32_t)value; break;
-    case LPT_OPT_POOL_WAVES: if (value != 4u && value != 8u && value != 16u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_WAVES: 4, 8 or 16"); r->pool_waves = (uint32_t)value; break;
-    case LPT_OPT_POOL_REFILL: if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_OPT_POOL_REFILL: 0..63"); r->pool_refill = (int)value; break;
-    case LPT_OPT_SPLIT_RAYS: r->split_rays = value; break;
-    case LPT_OPT_BUDGET_SPLIT: r->budget_split = value != 0; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_WAVES_PER_CU): if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_REFILL): if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_OCC_CELL_MILLI): r->occ_cell = (float)std::min<uint64_t>(value, 1000000u) * 1.0e-3f; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_STEP_BUDGET): r->step_budget = (uint32_t)std::min<uint64_t>(value, 1u << 20); break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_BUDGET_RAYS): r->budget_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PACKET_QUADS): r->packet_quads = value != 0; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_SPLIT_RAYS): r->split_rays = value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_BUDGET_SPLIT): r->budget_split = value != 0; break;
     case LPT_OPT_TAIL_LANES: r->tail_lanes = (uint32_t)std::min<uint64_t>(value, kTailMax); break;
     case LPT_OPT_COOP_RAYS: r->coop_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_set_option: unknown option %d", option);
@@ -1494,27 +1476,21 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
 int lpt_renderer_get_option(const lpt_renderer *r, int option, uint64_t *value) {
     if (!r || !value) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: null");
     switch (option) {
-    case LPT_OPT_MERGE_TRACE: *value = r->merge_trace; break;
     case LPT_OPT_PACKET_PRIMARY: *value = r->packet_primary; break;
-    case LPT_OPT_PIPE_RAYS: *value = r->pipe_rays; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PIPE_RAYS): *value = r->pipe_rays; break;
     case LPT_OPT_WAVEFRONT_RAYS: *value = r->wavefront_rays; break;
-    case LPT_OPT_REFILL: *value = (uint64_t)r->refill; break;
-    case LPT_OPT_TRACE_WAVES_PER_CU: *value = r->trace_waves_per_cu; break;
-    case LPT_OPT_SHADE_BLOCKS_PER_CU: *value = r->shade_blocks_per_cu; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_REFILL): *value = (uint64_t)r->refill; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_TRACE_WAVES_PER_CU): *value = r->trace_waves_per_cu; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_SHADE_BLOCKS_PER_CU): *value = r->shade_blocks_per_cu; break;
     case LPT_OPT_PATH_RAYS: *value = r->path_rays; break;
-    case LPT_OPT_PATH_WAVES_PER_CU: *value = r->path_waves_per_cu; break;
-    case LPT_OPT_PATH_REFILL: *value = (uint64_t)r->path_refill; break;
-    case LPT_OPT_OCC_CELL_MILLI: *value = (uint64_t)(r->occ_cell * 1000.0f + 0.5f); break;
-    case LPT_OPT_STEP_BUDGET: *value = r->step_budget; break;
-    case LPT_OPT_BUDGET_RAYS: *value = r->budget_rays; break;
-    case LPT_OPT_PACKET_QUADS: *value = r->packet_quads; break;
-    case LPT_OPT_POOL_RAYS: *value = r->pool_rays; break;
-    case LPT_OPT_POOL_SHADERS: *value = r->pool_shaders; break;
-    case LPT_OPT_POOL_ENTRIES: *value = r->pool_entries; break;
-    case LPT_OPT_POOL_WAVES: *value = r->pool_waves; break;
-    case LPT_OPT_POOL_REFILL: *value = (uint64_t)r->pool_refill; break;
-    case LPT_OPT_SPLIT_RAYS: *value = r->split_rays; break;
-    case LPT_OPT_BUDGET_SPLIT: *value = r->budget_split; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_WAVES_PER_CU): *value = r->path_waves_per_cu; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_REFILL): *value = (uint64_t)r->path_refill; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_OCC_CELL_MILLI): *value = (uint64_t)(r->occ_cell * 1000.0f + 0.5f); break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_STEP_BUDGET): *value = r->step_budget; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_BUDGET_RAYS): *value = r->budget_rays; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_PACKET_QUADS): *value = r->packet_quads; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_SPLIT_RAYS): *value = r->split_rays; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_BUDGET_SPLIT): *value = r->budget_split; break;
     case LPT_OPT_TAIL_LANES: *value = r->tail_lanes; break;
     case LPT_OPT_COOP_RAYS: *value = r->coop_rays; break;
     default: return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_get_option: unknown option %d", option);
@@ -1719,7 +1695,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
         // the one-round-trip step (kernels.h ray_step_pipe): 78 VGPRs, so 6 waves per SIMD instead of 8, ~3 % more nodes and ~12 % more
         // triangles fetched per ray — and still 1 % less time per frame at 8 M rays, 2 % for a 1 M-ray tile shard
-        // (profiles/r03_experiments_ab.txt); LPT_OPT_PIPE_RAYS 0 selects the two-round-trip step
+        // (profiles/r03_experiments_ab.txt); LPT_EXP_PIPE_RAYS 0 selects the two-round-trip step
         const bool pipe = n_rays <= r->pipe_rays;
         // persistent waves: about 2.5 primary rays per lane, between 8 waves per CU and all that fit (24 at 78 VGPRs, 32 at 59).  A 1/8
         // tile shard (1 M rays per launch) is best at 24 either way (round 3, span form, two-round-trip step: 8 / 12 / 16 / 24 / 32
@@ -1744,12 +1720,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         // angle, the walk visits several times the nodes, and the packet launch is a third of the frame (0.43 of 1.37 ms; 0.39 ms at 480x270,
         // where the per-ray launch needs 0.13).  LPT_OPT_PACKET_PRIMARY 2 (default): packets up to 1.8 mrad per pixel; 1: always; 0: never.
         const float pixel_rad = 2.0f * th / (float)std::max(r->h, 1u);
-        const bool packet = r->merge_trace && (r->packet_primary == 1u || (r->packet_primary == 2u && pixel_rad <= kPacketMaxPixelRad));
+        const bool packet = (r->packet_primary == 1u || (r->packet_primary == 2u && pixel_rad <= kPacketMaxPixelRad));
         tk.packet = packet;
         uint32_t seed = seed0;
-        // Traversal launches.  merged (default): closest-hit rays of bounce b+1 and shadow rays of bounce b, both
-        // produced by shade(b), are traced by ONE persistent launch (k_trace) — nb+1 traversal launches per frame
-        // instead of 2*nb; split (LPT_OPT_MERGE_TRACE 0): IntersectorPass and the shadow pass as separate launches.
+        // Traversal launches: closest-hit rays of bounce b+1 and shadow rays of bounce b, both produced by shade(b), are traced by
+        // ONE persistent launch (k_trace) — nb+1 traversal launches per frame instead of 2*nb.
         // the occluder-cache probe rides with the stats kernels only (kernels.h OccProbe); its table belongs to the renderer
         OccProbe occ{nullptr, 0u, 0.0f};
         if (r->stats && r->occ_table && r->occ_cell > 0.0f) occ = OccProbe{r->occ_table, kOccEntries - 1u, 1.0f / r->occ_cell};
@@ -1764,7 +1739,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const size_t tail_lds = tail ? sizeof(uint32_t) * tail_lds_words(r->sg->stats.max_depth) : 0u;
         // a TINY wavefront (fewer rays than the chip has wave slots): the per-bounce launches with EVERY ray traced by a whole wave (k_trace_coop over the queues) — a lane per
         // ray leaves the chip empty and the frame is one chain of dependent steps (64x36, 4 spp: k_path 0.72 ms per frame, the per-lane launches 0.83, this 0.39)
-        const bool coop_all = r->merge_trace && !r->stats && r->coop_rays && n_rays <= r->coop_rays;
+        const bool coop_all = !r->stats && r->coop_rays && n_rays <= r->coop_rays;
         auto trace = [&](int cb, int sb) {
             stage_begin(r, cb >= 0 ? ST_INTERSECT : ST_SHADOW, s);  // :457-464, :493-498
             const Queue qin = wf.q[(uint32_t)(cb < 0 ? 0 : cb) & 1u];
@@ -1790,12 +1765,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             }
             stage_end(r, s);
         };
-        // The pool kernel (pool_kernels.h) for wavefronts above the path kernel's range: one block of pool_waves waves per 16 wave slots of a CU, its LDS
-        // (traversal stacks of every wave + the rings) must fit the CU's 160 KB — a tree too deep for that takes the per-bounce launches
-        const uint32_t pool_entries = r->pool_entries ? r->pool_entries : 256u * r->pool_waves, pool_trace_cap = 64u * r->pool_waves;
-        const uint32_t pool_lds = pool_lds_bytes(sc.stack_entries, r->pool_waves, pool_entries, pool_trace_cap);
-        const bool use_pool = r->merge_trace && r->pool_rays && n_rays <= r->pool_rays && !(r->path_rays && n_rays <= r->path_rays) && !coop_all && pool_lds * (16u / r->pool_waves) <= 160u * 1024u;
-        if (r->merge_trace) {
+        {
             if (packet) {
                 // the primary rays: 64 consecutive queue entries are an 8x8-pixel patch of one sample — packet traversal (k_trace_packet)
                 stage_begin(r, ST_PRIMARY, s);
@@ -1807,11 +1777,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 if (r->stats) hipLaunchKernelGGL(k_trace_packet<true>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 else hipLaunchKernelGGL(k_trace_packet<false>, dim3(std::min(packets, cus * kPacketBlocksPerCu)), dim3(kTraceBlock), plds, s, sc, wf.q[0], wf.hits, wf.ctr, 0, quad_slots);
                 stage_end(r, s);
-            } else if (coop_all || (!(r->path_rays && n_rays <= r->path_rays) && !use_pool)) trace(0, -1);   // a path- or pool-kernel wavefront traces its primary rays itself
+            } else if (coop_all || !(r->path_rays && n_rays <= r->path_rays)) trace(0, -1);   // a path-kernel wavefront traces its primary rays itself
         }
         // A small wavefront (the tile shard of a multi-GPU frame): every bounce behind the primary hits in ONE persistent launch — the
         // passes of renderer.rs:484-509 without a chip-wide barrier between them (kernels.h k_path); same frame, same counters
-        const bool path = r->merge_trace && r->path_rays && n_rays <= r->path_rays && !coop_all;   // the primary hits are there, whichever kernel found them
+        const bool path = r->path_rays && n_rays <= r->path_rays && !coop_all;   // the primary hits are there, whichever kernel found them
         if (path) {
             stage_begin(r, ST_PATH, s);
             const uint32_t pblocks = std::min<uint32_t>(div_up(n_rays, kTraceBlock), std::max(8u, (cus * r->path_waves_per_cu) & ~7u));
@@ -1823,59 +1793,16 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
             else hipLaunchKernelGGL((k_path<false, false>), dim3(pblocks), dim3(kTraceBlock), plds, s, sc, probe, nz, p, wf.q[0], packet ? wf.hits : (const float4 *)nullptr, wf.Lsum, wf.ctr, seed0, gb, r->path_refill);
             stage_end(r, s);
         }
-        if (use_pool) {
-            stage_begin(r, ST_PATH, s);
-            const uint32_t blocks = cus * (16u / r->pool_waves);
-            const size_t need = (size_t)blocks * pool_entries * kPoolRec;
-            if (wf.pool_slab_elems < need) {
-                HIP_TRY(hipStreamSynchronize(s));
-                if (wf.pool_slab) HIP_TRY(hipFree(wf.pool_slab));
-                wf.pool_slab = nullptr; wf.pool_slab_elems = 0;
-                HIP_TRY(hipMalloc(&wf.pool_slab, sizeof(float4) * need));
-                wf.pool_slab_elems = need;
-            }
-            PoolArgs pa{wf.pool_slab, pool_entries, pool_trace_cap, std::min(r->pool_shaders, r->pool_waves), r->pool_refill, 256u, r->err_dev};
-            const float4 *h0 = packet ? wf.hits : (const float4 *)nullptr;
-            if (!r->dev->pool_attr_set) {   // more than 64 KB of dynamic LDS needs the attribute
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pool<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                r->dev->pool_attr_set = true;
-            }
-            const dim3 pg(blocks), pb(64u * r->pool_waves);
-            if (denoise) {
-                if (r->stats) hipLaunchKernelGGL((k_pool<true, true>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
-                else hipLaunchKernelGGL((k_pool<true, false>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
-            } else if (r->stats) hipLaunchKernelGGL((k_pool<false, true>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
-            else hipLaunchKernelGGL((k_pool<false, false>), pg, pb, pool_lds, s, sc, probe, nz, p, wf.q[0], h0, wf.Lsum, wf.ctr, seed0, gb, pa);
-            stage_end(r, s);
-        }
-        for (uint32_t b = 0; b < nb && !path && !use_pool; ++b) {
+        for (uint32_t b = 0; b < nb && !path; ++b) {
             seed += 1u;                          // :453, :487
             const Queue qin = wf.q[b & 1u], qout = wf.q[(b + 1u) & 1u];
-            if (!r->merge_trace) {
-                stage_begin(r, ST_INTERSECT, s);    // :457-464, :493-498
-                if (r->stats) hipLaunchKernelGGL(k_intersect<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.ctr, (int)b, r->refill);
-                else hipLaunchKernelGGL(k_intersect<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.ctr, (int)b, r->refill);
-                stage_end(r, s);
-            }
             stage_begin(r, ST_SHADE, s);            // :471-480, :502-508
             if (denoise && b == 0u)  // PrimaryRayPass: bounce-0 shading + G-buffer + motion (renderer.rs:466-481)
-                hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
-            else if (r->sort_queues & 4)   // the shading input regrouped by kind inside each block (lpt_renderer_set_sort_queues bit 4)
-                hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+                hipLaunchKernelGGL(k_shade<true>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
             else
-                hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
+                hipLaunchKernelGGL(k_shade<false>, dim3(shade_blocks), dim3(kBlock), 0, s, sc, probe, nz, p, qin, wf.hits, qout, wf.sq, wf.Lsum, wf.ctr, (int)b, seed, gb, r->sort_queues);
             stage_end(r, s);
-            if (r->merge_trace) {
-                trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);
-            } else {
-                stage_begin(r, ST_SHADOW, s);
-                if (r->stats) hipLaunchKernelGGL(k_shadow<true>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, wf.sq, wf.Lsum, wf.ctr, (int)b, r->refill);
-                else hipLaunchKernelGGL(k_shadow<false>, dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, wf.sq, wf.Lsum, wf.ctr, (int)b, r->refill);
-                stage_end(r, s);
-            }
+            trace(b + 1u < nb ? (int)(b + 1u) : -1, (int)b);
         }
         if (split) HIP_TRY(hipEventRecord(wf.done, s));
         HIP_TRY(hipGetLastError());
@@ -2087,17 +2014,6 @@ int lpt_renderer_synchronize(lpt_renderer *r) {
     return check_device_error(r);
 }
 
-#ifdef LPT_EXP_WAVETIMES
-// A/B builds only (kernels.h LPT_EXP_WAVETIMES): the per-wave timing records the traversal launches of lane `lane`'s last wavefront left in its straggler list
-int lpt_debug_read_wave_times(lpt_renderer *r, uint32_t lane, uint32_t *dst, uint32_t words) {
-    if (!r || lane >= (uint32_t)kMaxLanes || !r->wf[lane].strag || (size_t)words > 2u * r->wf[lane].ray_cap) return fail(LPT_ERR_INVALID_ARG, "lpt_debug_read_wave_times");
-    FLUSH_OR_RETURN(r);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(dst, r->wf[lane].strag, sizeof(uint32_t) * words, hipMemcpyDeviceToHost));
-    return LPT_OK;
-}
-#endif
-
 int lpt_renderer_radiance_device_ptr(lpt_renderer *r, void **ptr, size_t *bytes) {
     if (!r || !ptr) return fail(LPT_ERR_INVALID_ARG, "lpt_renderer_radiance_device_ptr: null");
     FLUSH_OR_RETURN(r);
@@ -2266,7 +2182,7 @@ int lpt_renderer_get_ray_counts(lpt_renderer *r, lpt_ray_counts *out) {
     out->shadow_nodes = t.shadow_nodes; out->shadow_tris = t.shadow_tris;
     out->wave_steps = t.wave_steps; out->live_lanes = t.live_lanes; out->node_lanes = t.node_lanes; out->tri_lanes = t.tri_lanes;
     out->primary = t.primary; out->packet_nodes = t.packet_nodes; out->packet_tris = t.packet_tris;
-    out->shadow_occluded = t.shadow_occluded; out->occluder_cache_found = t.occ_found; out->occluder_cache_hits = t.occ_hits;
+    out->shadow_occluded = t.shadow_occluded; out->occluder_cache_found = t.occ_found; out->occluder_cache_hits = t.occ_hits; out->wave_rays = t.wave_rays;
     return check_device_error(r);
 }
 

@@ -3,9 +3,9 @@
 // Stage kernels, one per pass the reference records in Renderer::raytrace
 // (reference crates/lib/src/renderer.rs:444-538):
 //   k_raygen      <- passes::RayPass           (:444-448)
-//   k_intersect   <- passes::IntersectorPass   (:458-463, :493-498)
+//   k_trace (+ k_trace_packet for bounce 0) <- passes::IntersectorPass (:458-463, :493-498) and the shadow rays the reference's
+//                    shading pass traces inline
 //   k_shade       <- passes::PrimaryRayPass / passes::ShadingPass (:472-479, :502-508)
-//   k_shadow      <- the shadow rays the reference's shading pass traces inline
 //   k_accumulate  <- passes::AccumulationPass  (:525-533)
 // Unlike the reference (full pixel grid per dispatch, one ray slot per pixel) live
 // paths are stream-compacted into a queue after every bounce with a wave64
@@ -94,11 +94,12 @@ struct FrameCounters {
     // power of two (bucket k: 2^k <= steps < 2^(k+1), k = 0..11)
     uint32_t max_steps;
     uint32_t step_hist[12];
+    uint32_t tail_rays;   // rays the waves of k_trace<.., TAIL> finished cooperatively, in place (one atomic per wave that got there)
 };
 __device__ __host__ __forceinline__ uint32_t &QC(FrameCounters *c, int b) { return b == 0 ? c->q0 : c->qs[2 * (b - 1) + 1]; }
 __device__ __host__ __forceinline__ uint32_t &SC(FrameCounters *c, int b) { return c->qs[2 * b]; }
 struct Totals { unsigned long long closest, shadow, shaded, nodes, tris, shadow_nodes, shadow_tris, wave_steps, live_lanes, node_lanes, tri_lanes,
-                                   primary, packet_nodes, packet_tris, shadow_occluded, occ_found, occ_hits; };   // mirrors lpt_ray_counts
+                                   primary, packet_nodes, packet_tris, shadow_occluded, occ_found, occ_hits, wave_rays; };   // mirrors lpt_ray_counts
 
 // Tile ownership.  Tile t (row-major over the tile grid) belongs to VIRTUAL rank t % V; the V virtual ranks are dealt to
 // the ranks in proportion to their weights (a rank that also assembles, reads back or filters the frame gets fewer tiles).  With
@@ -454,16 +455,6 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
                 if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
-#ifdef LPT_EXP_DUPMASK
-                // ceiling probe (A/B builds only, `make variant`): the hit-mask assembly of the first LPT_EXP_DUPMASK children a SECOND time on
-                // operands the compiler cannot see through — the same value OR-ed in again, so the frame does not change; what the launch loses is what these
-                // instructions cost where they stand
-                if (4 * half + j < LPT_EXP_DUPMASK) {
-                    uint32_t cb = child_bits4;
-                    asm volatile("" : "+v"(cb));
-                    if (tn <= tf) hitmask |= ((cb >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
-                }
-#endif
             }
         }
         rs.ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));
@@ -624,115 +615,6 @@ __device__ __forceinline__ void intersect_lights(const DScene &sc, f3 o, f3 d, H
 // dynamic LDS: sc.stack_entries * kTraceBlock uint2 (16-byte aligned, Guideline 17)
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
 
-// Persistent traversal: a fixed grid of waves, each owning a contiguous slice of the queue.
-// Whenever `refill` or fewer lanes still carry a live ray, the idle lanes pull the next rays of
-// the wave's own slice (a ballot + prefix count; no atomics), so lanes whose ray ended early
-// do not idle while the longest ray of the packet finishes.
-template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_intersect(DScene sc, Queue q, float4 *hits, FrameCounters *ctr, int bounce, int refill) {
-    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
-    ChunkPuller pl;
-    puller_init(pl, &ctr->ihead[bounce * 8 * 32], QC(ctr, bounce));
-    const uint32_t lane = threadIdx.x;
-    uint32_t n_nodes = 0, n_tris = 0;
-    uint32_t w_steps = 0, w_live = 0, w_node = 0, w_tri = 0;  // wave-uniform utilisation counters (STATS)
-    RayState rs;
-    bool active = false, finished = false;  // finished: traversal over, result still in registers
-    uint32_t ray = 0;
-    for (;;) {
-        const unsigned long long amask = __ballot(active);
-        const int n_active = __popcll(amask);
-        if (n_active <= refill) {
-            // results are written here, together with the refill, so that the emitter test and the store
-            // run for a batch of lanes instead of once per finishing lane
-            if (finished) {
-                intersect_lights(sc, rs.o, rs.d, rs.best);
-                hits[ray] = make_float4(rs.best.t, rs.best.u, rs.best.v, __uint_as_float(rs.best.prim));
-                finished = false;
-            }
-            puller_pull(pl);
-            if (pl.next < pl.end) {
-                const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
-                if (!active && idx < pl.end) {
-                    const float4 o4 = q.o[idx], d4 = q.d[idx];
-                    ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), LPT_T_INF);
-                    ray = idx;
-                    active = true;
-                }
-                pl.next = min(pl.end, pl.next + (uint32_t)(64 - n_active));
-            } else if (n_active == 0) break;
-        }
-        const uint32_t tris_before = n_tris;
-        if (STATS) {
-            w_steps++;
-            w_live += (uint32_t)__popcll(__ballot(active));
-            w_node += (uint32_t)__popcll(__ballot(active && rs.tg.y == 0u));
-        }
-        if (active && ray_step<false, STATS>(sc, rs, stack, n_nodes, n_tris)) {
-            active = false;
-            finished = true;
-        }
-        if (STATS) w_tri += (uint32_t)__popcll(__ballot(n_tris != tris_before));
-    }
-    if (STATS) {
-        atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
-        atomicAdd(&ctr->tris, (unsigned long long)n_tris);
-        if (lane == 0) {
-            atomicAdd(&ctr->wave_steps, (unsigned long long)w_steps);
-            atomicAdd(&ctr->live_lanes, (unsigned long long)w_live);
-            atomicAdd(&ctr->node_lanes, (unsigned long long)w_node);
-            atomicAdd(&ctr->tri_lanes, (unsigned long long)w_tri);
-        }
-    }
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_shadow(DScene sc, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce, int refill) {
-    uint2 *stack = reinterpret_cast<uint2 *>(lds_dyn) + threadIdx.x;
-    ChunkPuller pl;
-    puller_init(pl, &ctr->shead[bounce * 8 * 32], SC(ctr, bounce));
-    const uint32_t lane = threadIdx.x;
-    uint32_t n_nodes = 0, n_tris = 0;
-    RayState rs;
-    bool active = false, finished = false;
-    uint32_t ray = 0;
-    for (;;) {
-        const unsigned long long amask = __ballot(active);
-        const int n_active = __popcll(amask);
-        if (n_active <= refill) {
-            if (finished) {
-                if (rs.best.prim == 0xFFFFFFFFu) {  // unoccluded: deposit the light sample
-                    const uint32_t slot = __float_as_uint(sq.d[ray].w);
-                    const float4 c = sq.c[ray];
-                    float4 L = Lsum[slot];
-                    L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
-                    Lsum[slot] = L;
-                }
-                finished = false;
-            }
-            puller_pull(pl);
-            if (pl.next < pl.end) {
-                const uint32_t idx = pl.next + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
-                if (!active && idx < pl.end) {
-                    const float4 o4 = sq.o[idx], d4 = sq.d[idx];
-                    ray_begin(rs, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w);
-                    ray = idx;
-                    active = true;
-                }
-                pl.next = min(pl.end, pl.next + (uint32_t)(64 - n_active));
-            } else if (n_active == 0) break;
-        }
-        if (active && ray_step<true, STATS>(sc, rs, stack, n_nodes, n_tris)) {
-            active = false;
-            finished = true;
-        }
-    }
-    if (STATS) {
-        atomicAdd(&ctr->shadow_nodes, (unsigned long long)n_nodes);
-        atomicAdd(&ctr->shadow_tris, (unsigned long long)n_tris);
-    }
-}
-
 // Occluder-cache PROBE (STATS variants only): a table of the last occluding triangle per cell of a grid over the shadow
 // rays' origins.  The probe asks, for every finished shadow ray, what the cache would have answered at its start — is there an entry,
 // does that triangle occlude this ray (Woop test) — and then records the ray's own occluder.  Nothing about the traversal changes.
@@ -746,8 +628,7 @@ __device__ __forceinline__ uint32_t occ_key(const OccProbe &oc, f3 o) {
 // absent: -1).  Both queues were filled by the same shading pass; tracing them together halves the number of
 // traversal launches per frame and lets the short shadow rays fill the lanes that the tail of the closest-hit
 // queue leaves idle.  A wave drains closest-hit chunks first, then shadow chunks; a lane remembers which kind
-// of ray it carries.  Results are identical to k_intersect followed by k_shadow: the only shared state is
-// Lsum, which only the shadow part touches.
+// of ray it carries.  The only state the two kinds share is Lsum, which only the shadow part touches.
 // PIPE: ray_step_pipe (one memory round trip per step) instead of ray_step_any — same results, for launches of few rays.
 // ---- one ray, a whole wave (k_trace_coop, and the tail of k_trace) ----------------------------------------------------------------------------------
 // Eight lanes per node (lane j of a group tests child j), up to eight pending nodes of the ray per round.  The node stack (node indices) is one LDS
@@ -981,12 +862,6 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
-#ifdef LPT_EXP_WAVETIMES
-    // timing probe (A/B builds only, `make variant`; tools/dev/r05_wave_times.py): when did this wave start, find its queues dry, enter the tail, end — in
-    // 10 ns ticks of the constant clock, dumped into the (otherwise unused) straggler list: 8 words per wave and launch
-    const uint32_t wt_start = (uint32_t)wall_clock64();
-    uint32_t wt_dry = 0u, wt_tail = 0u, wt_ndry = 0u, wt_ntail = 0u, wt_steps = 0u;
-#endif
     for (;;) {
         const unsigned long long amask = __ballot(active);
         const int n_active = __popcll(amask);
@@ -1030,10 +905,6 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             const bool use_s = !(pc.next < pc.end);  // wave-uniform
             if (use_s) puller_pull<TAIL>(ps);
             const uint32_t nx = use_s ? ps.next : pc.next, en = use_s ? ps.end : pc.end;
-#ifdef LPT_EXP_WAVETIMES
-            if (!(nx < en) && !wt_dry) { wt_dry = (uint32_t)wall_clock64() | 1u; wt_ndry = (uint32_t)n_active; }
-            if (!(nx < en) && TAIL && n_active && n_active <= (int)tail) { wt_tail = (uint32_t)wall_clock64() | 1u; wt_ntail = (uint32_t)n_active; }
-#endif
             if (nx < en) {
                 const uint32_t idx = nx + (uint32_t)__popcll(~amask & ((1ull << lane) - 1ull));
                 if (!active && idx < en) {
@@ -1053,13 +924,11 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
                 // both queues are dry and few rays are left: the wave finishes them cooperatively, in place (tail_park / tail_walk; the host sets `tail` only without the stats)
                 TailArgs ta = {sc.nodes, sc.woop, sc.leaf_prim, sc.lights, sc.n_lights, sc.stack_entries, 0u, hits, sq.c, Lsum};
                 ta.n_live = tail_park<PIPE>(rs, amask, active, shadow, ray, reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2)));
+                if (lane == 0) atomicAdd(&ctr->tail_rays, ta.n_live);
                 tail_walk(ta);
                 break;
             }
         }
-#ifdef LPT_EXP_WAVETIMES
-        if (wt_dry) wt_steps++;
-#endif
         uint32_t dn = 0, dt = 0;
         if (STATS) {
             w_steps++;
@@ -1084,12 +953,6 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             if (shadow) { s_nodes += dn; s_tris += dt; } else { n_nodes += dn; n_tris += dt; }
         }
     }
-#ifdef LPT_EXP_WAVETIMES
-    if (lane == 0 && strag) {
-        uint32_t *o = strag + ((uint32_t)launch * 8192u + blockIdx.x) * 8u;
-        o[0] = wt_start; o[1] = wt_dry; o[2] = wt_tail; o[3] = (uint32_t)wall_clock64(); o[4] = wt_ndry; o[5] = wt_ntail; o[6] = wt_steps; o[7] = 0x57415645u;
-    }
-#endif
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
         atomicAdd(&ctr->tris, (unsigned long long)n_tris);
@@ -1705,13 +1568,12 @@ __device__ __forceinline__ void shade_hit(const DScene &sc, const DProbe &probe,
     }
 }
 
-template <bool GBUF, bool REGROUP = false>
+template <bool GBUF>
 __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
                                                   uint32_t seed_base, GBufArgs gb, int sorted) {
     __shared__ uint32_t lds[72];
     __shared__ float s_lut[256];
-    __shared__ uint8_t s_perm[REGROUP ? 256 : 4];
     s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];  // kBlock == 256
     __syncthreads();
     const uint32_t count = QC(ctr, bounce);
@@ -1723,46 +1585,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < rounded; i0 += stride) {
         ShadeOut so;
         so.want_next = false; so.want_shadow = false; so.is_surface = false;
-        uint32_t i = i0;
-        if (REGROUP) {
-            // IN-BLOCK REGROUP of what shading reads (VERDICT r03 #2 ii): the block's 256 hits are dealt to its threads by kind — surface hits
-            // first, then emitter hits, then misses, then the slots past the end of the queue — so that a wave runs ONE branch of the shading
-            // code with all its lanes instead of three with some.  The permutation stays inside the block's own 256-entry window of the
-            // queue (no extra traffic beyond one coalesced re-read of the hit record); results are keyed by pixel slot, so the frame does
-            // not change by a bit.
-            uint32_t key = 3u;
-            if (i0 < count) {
-                const uint32_t prim0 = __float_as_uint(ld_nt(hits + i0).w);
-                key = prim0 == 0xFFFFFFFFu ? 2u : ((prim0 & LPT_LIGHT_BIT) ? 1u : 0u);
-            }
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            unsigned long long mine = 0ull;
-            uint32_t cnt_k = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
-                const unsigned long long m = __ballot(key == k);
-                if (key == k) mine = m;
-                if (lane == k) cnt_k = (uint32_t)__popcll(m);
-            }
-            if (lane < 4u) lds[lane * 4u + wave] = cnt_k;   // [key][wave]
-            __syncthreads();
-            if (threadIdx.x < 16u) {
-                const uint32_t c = lds[threadIdx.x];
-                uint32_t incl = c;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const uint32_t v = __shfl_up(incl, off);
-                    if ((int)lane >= off) incl += v;
-                }
-                lds[16u + threadIdx.x] = incl - c;
-            }
-            __syncthreads();
-            const uint32_t rank = lds[16u + key * 4u + wave] + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
-            __syncthreads();   // lds[0..32) is read; s_perm is written next
-            s_perm[rank] = (uint8_t)threadIdx.x;
-            __syncthreads();
-            i = (i0 - threadIdx.x) + (uint32_t)s_perm[threadIdx.x];
-        }
+        const uint32_t i = i0;
         if (i < count) {
             const float4 d4 = ld_nt(qin.d + i), T4 = ld_nt(qin.T + i), h4 = ld_nt(hits + i);
             const uint32_t slot = __float_as_uint(d4.w);
@@ -2229,6 +2052,9 @@ __global__ __launch_bounds__(64) void k_finish_frame(FrameCounters *ctr, Totals 
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
     tot->shadow_occluded += ctr->shadow_occluded; tot->occ_found += ctr->occ_found; tot->occ_hits += ctr->occ_hits;
+    unsigned long long wr = ctr->tail_rays;
+    for (uint32_t l = 0; l <= bounces && l <= (uint32_t)kMaxBounces; ++l) wr += ctr->strag_count[l];
+    tot->wave_rays += wr;
 }
 
 // mean radiance (a = 1 where sampled) and sRGB8 (SPEC §13.2)

@@ -49,8 +49,6 @@ PIPELINES = {
     # shipped form of these launches — tails finished in place instead of a budget — runs in the "default" arm (where the frame takes the per-bounce launches) and
     # in tests/test_gpu_tail.py
     "per_bounce": {"path_rays": 0, "step_budget": 16, "tail_lanes": 0, "coop_rays": 0},
-    # round 5: the CU-local pool of trace and shade work (k_pool): records handed between the waves of a block through LDS rings, hits shaded by kind
-    "pool": {"path_rays": 0, "pool_rays": 0x7FFFFFFF, "packet_primary": 1, "coop_rays": 0},
     # the configuration as shipped: nothing forced (kernel choice by ray count and pixel footprint — a wave per ray for the tiny frames many tests render, LPT_OPT_COOP_RAYS —,
     # tails in place, quad packets) — ADVICE r04.  The other arms switch the tiny-wavefront rule off (coop_rays 0) so that they exercise the kernel they name at every size
     "default": {},
@@ -60,7 +58,7 @@ PIPELINES = {
 @pytest.fixture(params=list(PIPELINES))
 def pipeline(request, monkeypatch):
     """Runs a test body over every form of the frame pipeline (PIPELINES above) and over the shipped defaults.  The library picks between the forms by
-    the wavefront's ray count (LPT_OPT_PATH_RAYS, LPT_OPT_POOL_RAYS); all of them must give the oracle's frame at every size.  Modules opt in with
+    the wavefront's ray count (LPT_OPT_COOP_RAYS, LPT_OPT_PATH_RAYS); all of them must give the oracle's frame at every size.  Modules opt in with
     `pytestmark = pytest.mark.usefixtures("pipeline")`."""
     from loupiote_amd import api
     # the shipped defaults pick k_path for the small frames most tests render — what the "path" arm already forces; the arm earns its time where the

@@ -42,7 +42,7 @@ def test_struct_layouts():
     assert A.LIGHT_DT.itemsize == 64
     assert A.INSTANCE_DT.itemsize == 80
     assert A.HIT_DT.itemsize == 16
-    assert A.lib().lpt_abi_version() == 5
+    assert A.lib().lpt_abi_version() == 6
     assert A.lib().lpt_max_per_pixel_bytes() == 48
 
 

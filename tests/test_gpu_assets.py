@@ -15,7 +15,7 @@ from loupiote_amd import testing as T
 from oracle import gltf_oracle as G, orc
 from test_loader import _jpeg, make_gltf, png_bytes
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 
 
 def _grid(nx, nz, size, y, bump, seed):

@@ -7,7 +7,7 @@ import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
 from oracle import harness
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 TOL = 1e-5
 
 
@@ -160,7 +160,7 @@ def test_raytrace_n_equals_n_sequential_calls(device, atrium):
 
 @pytest.mark.parametrize("budget", [1, 9, 24])
 def test_step_budget_and_the_cooperative_kernel_give_the_same_frame(device, atrium, budget):
-    """per-bounce launches with a step budget (LPT_OPT_STEP_BUDGET): a ray that is not finished after `budget` traversal steps is dropped by the per-lane kernel
+    """per-bounce launches with a step budget (LPT_EXP_STEP_BUDGET): a ray that is not finished after `budget` traversal steps is dropped by the per-lane kernel
     and traced again by a whole wave (k_trace_coop: eight lanes per node, up to eight pending nodes per round).  budget 1 sends every ray of bounces 1.. that way,
     9 about half of them, 24 the long ones — the frame and the ray counts are the oracle's on the 262 144-triangle scene"""
     desc, osc = atrium

@@ -10,7 +10,7 @@ import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
 from oracle import harness
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 W, H, DEPTH = 203, 117, 5
 
 
@@ -260,13 +260,13 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
     """The default for a frame this small: bounce 0 per ray (packet traversal, k_trace_packet: one tree walk per 8x8-pixel patch, is chosen by pixel
     footprint — packet_primary = 1 forces it), then every later bounce in ONE launch (k_path); path_rays = 0 selects the per-bounce launches of renderer.rs:484-509 (k_shade + k_trace, one
     memory round trip per traversal step: ray_step_pipe), pipe_rays = 0 their two-round-trip step, packet_primary = 0 per-ray traversal
-    for bounce 0 too, packet_quads = 0 packets of one sample over 8x8 pixels instead of four samples over 4x4, merge_trace = 0 the split k_intersect / k_shadow launches.  The order of the tests differs, the frame and the ray
+    for bounce 0 too, packet_quads = 0 packets of one sample over 8x8 pixels instead of four samples over 4x4.  The order of the tests differs, the frame and the ray
     counts do not (lpt_renderer_set_option: no environment variable selects a kernel)."""
     _, sg, pr = cornell
     view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
     ref, oc = harness.render_oracle(cornell_glb, W, H, DEPTH, 4)
     variants = ({}, {"packet_primary": 1}, {"packet_primary": 1, "packet_quads": 0}, {"path_rays": 0}, {"path_rays": 0, "packet_primary": 1}, {"path_rays": 0, "pipe_rays": 0, "packet_primary": 1},
-                {"path_rays": 0, "pipe_rays": 30000}, {"merge_trace": 0}, {"packet_primary": 0}, {"packet_primary": 0, "pipe_rays": 0},
+                {"path_rays": 0, "pipe_rays": 30000}, {"packet_primary": 0}, {"packet_primary": 0, "pipe_rays": 0},
                 {"path_waves_per_cu": 3, "path_refill": 20, "packet_primary": 1}, {"path_refill": 63}, {"path_refill": 0},
                 # the step budget: rays not finished after n steps are dropped by the per-lane kernel and traced again by a whole wave (k_trace_coop);
                 # n = 1: every ray of the per-bounce launches goes that way
@@ -287,14 +287,14 @@ def test_every_kernel_variant_gives_the_oracle_frame(device, cornell, cornell_gl
         c = r.ray_counts()
         assert (c.closest, c.shadow, c.shaded) == (oc.closest, oc.shadow, oc.shaded), opts
         # which kernel traced bounce 0: packets only where asked for — the default (2) picks by pixel footprint, and a frame this small is traced per ray
-        assert c.primary == (4 * W * H if packet == 1 and "merge_trace" not in opts else 0), opts
+        assert c.primary == (4 * W * H if packet == 1 else 0), opts
         r.close()
 
 
 @pytest.mark.parametrize("samples", [4, 8, 12, 6])
 def test_packets_of_four_samples_on_a_dense_frame(device, cornell, cornell_glb, samples):
     """k_trace_packet on a frame of whole 32x8 tiles (the 203x117 frames above are not): with a multiple of four samples in the wavefront a packet is the
-    four samples of a 4x4-pixel quarter of an 8x8 patch (LPT_OPT_PACKET_QUADS, default), else — 6 samples, or the option off — one sample of the whole patch.
+    four samples of a 4x4-pixel quarter of an 8x8 patch (LPT_EXP_PACKET_QUADS, default), else — 6 samples, or the option off — one sample of the whole patch.
     Which 64 rays share a tree walk changes nothing: the frame is the oracle's, the primary rays are all traced by packets."""
     _, sg, pr = cornell
     size = (256, 136)

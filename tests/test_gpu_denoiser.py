@@ -7,7 +7,7 @@ import pytest
 import loupiote_amd as lp
 from loupiote_amd import dist as D, testing as T
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 
 
 def _setup(device, glb, w, h, bounces):

@@ -8,7 +8,7 @@ import loupiote_amd as lp
 from loupiote_amd import testing as T
 from oracle import gltf_oracle as G, orc
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 
 QUAD_POS = np.array([[-1, 0, -1, 0], [1, 0, -1, 0], [1, 0, 1, 0], [-1, 0, 1, 0]], np.float32)
 QUAD_IDX = np.array([0, 2, 1, 0, 3, 2], np.uint32)

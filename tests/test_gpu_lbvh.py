@@ -9,7 +9,7 @@ import loupiote_amd as lp
 from loupiote_amd import scenes, testing as T
 from oracle import harness
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the four arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, k_pool, the shipped defaults
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("pipeline")]   # every test body over the three arms of tests/conftest.py PIPELINES: k_path, the per-bounce launches, the shipped defaults
 
 
 def _rays(n, lo, hi, seed):

@@ -80,14 +80,13 @@ def test_tile_shards_sum_to_full_frame(device, cornell_glb):
     assert closest == fc.closest
 
 
-def test_split_and_merged_traversal_launches_agree(device, cornell_glb):
-    """merge_trace = 0 (IntersectorPass and the shadow pass as separate launches, k_intersect / k_shadow), the merged per-bounce
-    launches (k_trace: both in one persistent launch) and the path kernel (every bounce in one launch) give the same bits and the
-    same ray counts"""
-    merged, cm = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"path_rays": 0})
-    split, cs = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"merge_trace": 0})
-    path, cp = T.render_hip(device, cornell_glb, 160, 96, 6, 3)
-    assert merged.tobytes() == split.tobytes() == path.tobytes()
+def test_per_bounce_launches_and_path_kernel_agree(device, cornell_glb):
+    """the per-bounce launches (k_trace: closest-hit and shadow rays in one persistent launch), the same with the two-round-trip step, and the path
+    kernel (every bounce in one launch) give the same bits and the same ray counts"""
+    merged, cm = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"path_rays": 0, "coop_rays": 0})
+    plain, cs = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"path_rays": 0, "coop_rays": 0, "pipe_rays": 0})
+    path, cp = T.render_hip(device, cornell_glb, 160, 96, 6, 3, options={"coop_rays": 0})
+    assert merged.tobytes() == plain.tobytes() == path.tobytes()
     assert (cm.closest, cm.shadow, cm.shaded) == (cs.closest, cs.shadow, cs.shaded) == (cp.closest, cp.shadow, cp.shaded)
 
 

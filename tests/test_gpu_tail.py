@@ -14,7 +14,7 @@ from oracle import harness
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PER_BOUNCE = {"path_rays": 0, "pool_rays": 0, "coop_rays": 0}   # coop_rays 0: the tiny-wavefront rule (a wave per ray) would take the small frames here
+PER_BOUNCE = {"path_rays": 0, "coop_rays": 0}   # coop_rays 0: the tiny-wavefront rule (a wave per ray) would take the small frames here
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +46,7 @@ def _render(device, sg, pr, size, depth, frames, options, view, shard=None):
     r.raytrace_n(view, frames)
     img, c = r.read_radiance(), r.ray_counts()
     r.close()
+    _render.wave_rays = c.wave_rays    # rays a whole wave finished (tail in place / step budget): lets a test see that the path ran
     return img, (c.closest, c.shadow, c.shaded)
 
 
@@ -101,7 +102,9 @@ def test_config4_at_full_size_and_its_eighth_shard_with_the_tail_in_place(device
     sg = lp.SceneGPU.new_from_scene(scenes.to_product(desc), device)
     pr = lp.ProbeGPU(device, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
-    img, counts = _render(device, sg, pr, (1920, 1080), 8, 4, dict(PER_BOUNCE, tail_lanes=4, budget_rays=0x7FFFFFFF), view)
+    # wavefront_rays / split_rays: really ONE wavefront (the automatic cut into two pieces would switch the tail off — ADVICE r05)
+    img, counts = _render(device, sg, pr, (1920, 1080), 8, 4, dict(PER_BOUNCE, tail_lanes=4, budget_rays=0x7FFFFFFF, wavefront_rays=1 << 24, split_rays=0), view)
+    assert _render.wave_rays > 1000, _render.wave_rays   # waves did finish their last rays cooperatively
     assert list(counts) == g["cfg4_counts"].tolist()
     assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(g["cfg4_sha256"])
     shard = {}

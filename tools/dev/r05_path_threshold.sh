@@ -18,6 +18,6 @@ for sz in ${SIZES:-192x108 256x144 320x180 384x216 448x252 512x288 640x360}; do
   w=${sz%x*}; h=${sz#*x}
   for rep in 1 2; do
     run path_${sz}_$rep --width $w --height $h --opt path_rays=2147483647
-    run perbounce_${sz}_$rep --width $w --height $h --opt path_rays=0 --opt pool_rays=0
+    run perbounce_${sz}_$rep --width $w --height $h --opt path_rays=0
   done
 done

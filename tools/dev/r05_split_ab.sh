@@ -1,5 +1,5 @@
 #!/bin/bash
-# one solo wavefront with its tails in place against two pieces on two lanes, around LPT_OPT_SPLIT_RAYS: tools/dev/r05_split_ab.sh <out>
+# one solo wavefront with its tails in place against two pieces on two lanes, around LPT_EXP_SPLIT_RAYS: tools/dev/r05_split_ab.sh <out>
 OUT=gpurun_out/$1
 mkdir -p $OUT
 run() {

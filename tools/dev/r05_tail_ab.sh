@@ -19,5 +19,5 @@ for rep in 1 2 3; do
 done
 for t in 0 3 4; do run sh4_t${t} --emulate-shard 4 --opt tail_lanes=$t; done
 for t in 0 3 4; do run sh16_t${t} --emulate-shard 16 --opt tail_lanes=$t; done
-for t in 0 3 4; do run f480_t${t} --width 480 --height 270 --opt path_rays=0 --opt pool_rays=0 --opt tail_lanes=$t; done
-for t in 0 3 4; do run f960_t${t} --width 960 --height 540 --opt path_rays=0 --opt pool_rays=0 --opt tail_lanes=$t; done
+for t in 0 3 4; do run f480_t${t} --width 480 --height 270 --opt path_rays=0 --opt tail_lanes=$t; done
+for t in 0 3 4; do run f960_t${t} --width 960 --height 540 --opt path_rays=0 --opt tail_lanes=$t; done

@@ -48,7 +48,7 @@ for k in range(cases):
     desc, sg, pr = world[k % len(world)]
     size = (int(rng.integers(17, 420)), int(rng.integers(9, 260)))
     depth, spp, frames = int(rng.integers(1, 9)), int(rng.integers(1, 6)), int(rng.integers(1, 3))
-    base = {"path_rays": 0, "pool_rays": 0, "step_budget": 0, "tail_lanes": 0, "coop_rays": 0}
+    base = {"path_rays": 0, "step_budget": 0, "tail_lanes": 0, "coop_rays": 0}
     opts = dict(base, tail_lanes=int(rng.integers(1, 9)), refill=int(rng.integers(0, 64)), trace_waves_per_cu=int(rng.choice([0, 1, 2, 5, 24, 32])),
                 pipe_rays=int(rng.choice([0, 0x7FFFFFFF])), packet_primary=int(rng.integers(0, 3)), wavefront_rays=int(rng.choice([4194304, 20000, 70000])))
     if mode == "coop":

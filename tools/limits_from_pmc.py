@@ -29,7 +29,7 @@ def kernel_source_hash():
     """sha256 (16 hex digits) over the device code the counters were measured on: bench.py compares it with the tree it runs from and marks the replayed
     figures `stale` when they differ (the same function lives in bench.py)"""
     h = hashlib.sha256()
-    for f in ("kernels.h", "pool_kernels.h", "device_math.h"):
+    for f in ("kernels.h", "device_math.h"):
         h.update(open(os.path.join(ROOT, "loupiote_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
