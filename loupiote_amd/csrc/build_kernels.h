@@ -8,9 +8,9 @@
 //                   (Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012)
 //   k_lbvh_fit      boxes bottom-up; the second thread to reach a node continues (atomic flags)
 //   k_lbvh_collapse one launch per LEVEL of the wide tree: every 8-wide node opens its binary subtree greedily
-//                   (largest box first) into <= 8 children, subtrees of <= 3 triangles become leaf children;
+//                   (largest box first) into <= 8 children, subtrees of <= 2 triangles become leaf children;
 //                   children get octant-ordered slots; an exclusive scan over the level gives child / triangle bases
-//   k_lbvh_emit     node topology (imask, meta, bases), leaf order (leaf_prim, tri_slot), the next level's work list
+//   k_lbvh_emit     node topology (imask, leaf masks, bases), leaf order (leaf_prim, tri_slot), the next level's work list
 //   k_refit_level   (kernels.h) then fills every node's grid origin / exponents / quantised planes bottom-up.
 // The tree only decides WHICH boxes are visited; hits are decided by the Woop test and the (t, prim id) tie rule,
 // so a scene built here renders bit-identically to one built by the host SAH builder (tests/test_gpu_lbvh.py).
@@ -135,7 +135,7 @@ struct LbvhLevel {
 constexpr int kEmptyRef = 0x7FFFFFFF;
 
 __device__ __forceinline__ uint32_t lbvh_count(const LbvhTree &T, int ref) { return ref >= 0 ? T.last[ref] - T.first[ref] + 1u : 1u; }
-__device__ __forceinline__ bool lbvh_openable(const LbvhTree &T, int ref) { return ref >= 0 && lbvh_count(T, ref) > 3u; }
+__device__ __forceinline__ bool lbvh_openable(const LbvhTree &T, int ref) { return ref >= 0 && lbvh_count(T, ref) > 2u; }   // a leaf child carries one or two triangles (common.h Node8)
 
 __global__ __launch_bounds__(64) void k_lbvh_collapse(LbvhTree T, LbvhLevel L) {
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,33 +201,29 @@ __global__ __launch_bounds__(64) void k_lbvh_emit(LbvhTree T, LbvhLevel L, const
                                                    uint32_t next_first, uint32_t tri_first, uint4 *nodes, uint32_t *leaf_prim, uint32_t *tri_slot, int *next_items) {
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= L.n_items) return;
-    const uint32_t child_base = next_first + inner_off[it], tri_base = tri_first + tri_off[it];
-    uint32_t imask = 0u, rel = 0u, toff = 0u;
-    uint32_t meta[8];
+    const uint32_t child_base = next_first + inner_off[it], tri_base = (level_first + it) * kNodeTris;   // fixed triangle places: 16 * node + 2 * slot + k (common.h Node8)
+    uint32_t imask = 0u, rel = 0u, leaf1 = 0u, leaf2 = 0u;
+    (void)tri_off; (void)tri_first;
     for (int s = 0; s < 8; ++s) {
         const int ref = L.kid_ref[8 * (size_t)it + s];
-        meta[s] = 0u;
         if (ref == kEmptyRef) continue;
         if (lbvh_openable(T, ref)) {
             imask |= 1u << s;
-            meta[s] = 0x20u | (24u + (uint32_t)s);
             next_items[inner_off[it] + rel++] = ref;
         } else {
             const uint32_t cnt = lbvh_count(T, ref);
             const uint32_t first = ref >= 0 ? T.first[ref] : (uint32_t)~ref;
-            meta[s] = (((1u << cnt) - 1u) << 5) | toff;
+            leaf1 |= 1u << s;
+            if (cnt == 2u) leaf2 |= 1u << s;
             for (uint32_t k = 0; k < cnt; ++k) {
                 const uint32_t prim = T.sorted_tri[first + k];
-                leaf_prim[tri_base + toff + k] = prim;
-                tri_slot[prim] = tri_base + toff + k;
+                leaf_prim[tri_base + 2u * (uint32_t)s + k] = prim;
+                tri_slot[prim] = tri_base + 2u * (uint32_t)s + k;
             }
-            toff += cnt;
         }
     }
-    uint4 *nw = nodes + 5u * (size_t)(level_first + it);
-    nw[0] = make_uint4(0u, 0u, 0u, imask << 24);  // origin / exponents: k_refit_level
-    nw[1] = make_uint4(child_base, tri_base, meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24),
-                       meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24));
+    uint4 *nw = nodes + 4u * (size_t)(level_first + it);
+    nw[0] = make_uint4(0u, 0u, (imask << 8) | (leaf1 << 16) | (leaf2 << 24), child_base);  // origin / exponents / planes: k_refit_level
 }
 
 // scene bounds of the baked triangles (positions of the shading records): per-block reduction, then ordered-int atomics

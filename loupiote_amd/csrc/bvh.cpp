@@ -55,7 +55,8 @@ void woop_from_triangle(const float p0[3], const float p1[3], const float p2[3],
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 3;  // a leaf child of an 8-wide node carries at most 3 triangles
+constexpr uint32_t kLeafMax = 2;  // a leaf child of an 8-wide node carries at most 2 triangles (common.h Node8: fixed triangle places, leaf masks).  The SAH collapse rarely
+                                  // wanted more: of the bench scene's 156 059 leaves 2 914 had three; capped, a ray visits 13.60 nodes instead of 13.58 and tests 4.15 triangles for 4.24
 constexpr uint32_t kMaxDepth = 30;  // traversal stack is sized from this
 
 struct Box {
@@ -437,8 +438,8 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         out.nodes.push_back(root);
         WoopTri z;
         memset(&z, 0, sizeof z);
-        out.woop.push_back(z);
-        out.leaf_prim.push_back(LPT_INVALID_INDEX);
+        out.woop.assign(kNodeTris, z);
+        out.leaf_prim.assign(kNodeTris, LPT_INVALID_INDEX);
         out.max_depth = 1;
         out.level_start = {0u, 1u};
         return LPT_OK;
@@ -488,8 +489,11 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     std::vector<Pending> queue;
     queue.push_back({0, 1});
     out.nodes.resize(1);
-    out.woop.reserve(n);
-    out.leaf_prim.reserve(n);
+    {   // the scene grid of the node origins, from the padded triangle boxes (the root's box)
+        const Box &rb = b.nodes[0].box;
+        scene_grid(rb.lo, rb.hi, out.grid_lo, out.grid_step);
+    }
+    uint32_t tris_placed = 0;
     uint32_t max_depth = 1;
     out.level_start.clear();
     for (size_t w = 0; w < queue.size(); ++w) {
@@ -556,11 +560,14 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
 
         Node8 node;
         memset(&node, 0, sizeof node);
-        node.px = nb.lo[0]; node.py = nb.lo[1]; node.pz = nb.lo[2];
+        float org[3];   // the node's origin: the grid point at or below its box minimum
+        node.ox = grid_snap(nb.lo[0], out.grid_lo[0], out.grid_step[0], org[0]);
+        node.oy = grid_snap(nb.lo[1], out.grid_lo[1], out.grid_step[1], org[1]);
+        node.oz = grid_snap(nb.lo[2], out.grid_lo[2], out.grid_step[2], org[2]);
         double scale[3];
         uint8_t *eb[3] = {&node.ex, &node.ey, &node.ez};
         for (int a = 0; a < 3; ++a) {
-            const double ext = (double)nb.hi[a] - (double)nb.lo[a];
+            const double ext = (double)nb.hi[a] - (double)org[a];
             int e = -126;
             if (ext > 0.0) {
                 int k;
@@ -571,26 +578,31 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
             scale[a] = std::ldexp(1.0, e);
         }
         node.child_base = (uint32_t)queue.size();
-        node.tri_base = (uint32_t)out.woop.size();
-        uint32_t tri_off = 0;
+        if (out.woop.size() < (w + 1) * kNodeTris) {
+            WoopTri hole;
+            memset(&hole, 0, sizeof hole);
+            out.woop.resize((w + 1) * kNodeTris, hole);
+            out.leaf_prim.resize((w + 1) * kNodeTris, LPT_INVALID_INDEX);
+        }
         for (int sl = 0; sl < 8; ++sl) {
             const int i = kid_in_slot[sl];
             uint8_t *q[6] = {&node.qlox[sl], &node.qloy[sl], &node.qloz[sl], &node.qhix[sl], &node.qhiy[sl], &node.qhiz[sl]};
-            if (i < 0) {  // empty slot: inverted box, meta 0
+            if (i < 0) {  // empty slot: inverted box, in no mask
                 *q[0] = *q[1] = *q[2] = 255;
                 *q[3] = *q[4] = *q[5] = 0;
                 continue;
             }
             const BuildNode &c = b.nodes[kids[i].node];
             for (int a = 0; a < 3; ++a) {
-                const double lo = std::floor(((double)c.box.lo[a] - (double)nb.lo[a]) / scale[a]);
-                const double hi = std::ceil(((double)c.box.hi[a] - (double)nb.lo[a]) / scale[a]);
+                const double lo = std::floor(((double)c.box.lo[a] - (double)org[a]) / scale[a]);
+                const double hi = std::ceil(((double)c.box.hi[a] - (double)org[a]) / scale[a]);
                 *q[a] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
                 *q[3 + a] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
             }
             if (kids[i].leaf) {
-                // leaf child: unary triangle count in the top 3 bits, offset from tri_base in the low 5
-                node.meta[sl] = (uint8_t)((((1u << c.pcount) - 1u) << 5) | tri_off);
+                // leaf child: its one or two triangles at their fixed places
+                node.leaf1 |= (uint8_t)(1u << sl);
+                if (c.pcount == 2u) node.leaf2 |= (uint8_t)(1u << sl);
                 stat_leaf_tris[c.pcount]++;
                 sah += (double)c.box.half_area() * c.pcount * 0.3;
                 for (uint32_t t = 0; t < c.pcount; ++t) {
@@ -598,12 +610,12 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
                     const lpt_vertex *v = &out.tri_verts[3 * (size_t)prim];
                     WoopTri wt;
                     woop_from_triangle(v[0].position, v[1].position, v[2].position, wt);
-                    out.woop.push_back(wt);
-                    out.leaf_prim.push_back(prim);
+                    const size_t place = w * kNodeTris + 2u * (size_t)sl + t;
+                    out.woop[place] = wt;
+                    out.leaf_prim[place] = prim;
+                    tris_placed++;
                 }
-                tri_off += c.pcount;
             } else {
-                node.meta[sl] = (uint8_t)(0x20u | (24u + (uint32_t)sl));
                 node.imask |= (uint8_t)(1u << sl);
                 queue.push_back({kids[i].node, depth + 1});
             }
@@ -622,7 +634,13 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     }
     out.max_depth = max_depth;
     out.level_start.push_back((uint32_t)out.nodes.size());
-    if (out.woop.size() != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %zu of %u triangles referenced", out.woop.size(), n);
+    if (tris_placed != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %u of %u triangles referenced", tris_placed, n);
+    {   // whole nodes' worth of places for every node (the last levels' nodes have no children of their own to make the arrays grow)
+        WoopTri hole;
+        memset(&hole, 0, sizeof hole);
+        out.woop.resize(out.nodes.size() * kNodeTris, hole);
+        out.leaf_prim.resize(out.nodes.size() * kNodeTris, LPT_INVALID_INDEX);
+    }
     out.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return LPT_OK;
 }

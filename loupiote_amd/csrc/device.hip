@@ -328,31 +328,39 @@ static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
 // Fills sg->nodes / woop / leaf_prim / tri_slot / node_lo / node_hi / level_start from the baked triangles that are
 // already on the device (sg->d.tri_verts).  `woop_prim` = the Woop maps in prim order (host, SPEC §6).
 // `host_woop`: the Woop maps in prim order on the host (upload path) or nullptr when `dev_woop` (device, prim order) is given.
+// Scene bounds from the baked triangles on the device (blocking), and what follows from them for every kernel that pads a triangle or writes a node: the scene-wide part
+// of the triangle padding (bvh.cpp padded_box; it never shrinks — a pad a little too wide costs nothing) and the scene grid of the node origins (common.h scene_grid; the
+// padding is far inside the grid's slack).  Before a build and before every refit.
+static int scene_bounds_and_grid(lpt_scene_gpu *sg, uint32_t n, hipStream_t s, float blo[3], float bhi[3], bool keep_pad) {
+    int *db = nullptr, hb[6];
+    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    HIP_TRY(hipMalloc(&db, sizeof init));
+    HIP_TRY(hipMemcpyAsync(db, init, sizeof init, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>(div_up(n, 256u), 1024u)), dim3(256), 0, s, sg->d, n, db);
+    HIP_TRY(hipMemcpyAsync(hb, db, sizeof hb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(db);
+    for (int a = 0; a < 6; ++a) { const int o = hb[a] >= 0 ? hb[a] : hb[a] ^ 0x7FFFFFFF; float f; memcpy(&f, &o, 4); (a < 3 ? blo[a] : bhi[a - 3]) = f; }
+    float now_abs = 0.0f;
+    for (int a = 0; a < 3; ++a) now_abs = std::max(now_abs, std::max(fabsf(blo[a]), fabsf(bhi[a])));
+    sg->max_abs = keep_pad ? std::max(sg->max_abs, now_abs) : now_abs;
+    sg->d.pad_abs = kScenePad * sg->max_abs;   // (renderers read sg->d at submission)
+    scene_grid(blo, bhi, sg->d.grid_lo, sg->d.grid_step);
+    return LPT_OK;
+}
+
 static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, const float4 *dev_woop, hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
     float blo[3], bhi[3];
-    {   // scene bounds from the baked triangles on the device
-        int *db = nullptr, hb[6];
-        const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-        HIP_TRY(hipMalloc(&db, sizeof init));
-        HIP_TRY(hipMemcpyAsync(db, init, sizeof init, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>(div_up(n, 256u), 1024u)), dim3(256), 0, s, sg->d, n, db);
-        HIP_TRY(hipMemcpyAsync(hb, db, sizeof hb, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        hipFree(db);
-        for (int a = 0; a < 6; ++a) { const int o = hb[a] >= 0 ? hb[a] : hb[a] ^ 0x7FFFFFFF; float f; memcpy(&f, &o, 4); (a < 3 ? blo[a] : bhi[a - 3]) = f; }
-    }
+    { const int bst = scene_bounds_and_grid(sg, n, s, blo, bhi, false); if (bst != LPT_OK) return bst; }
     float binv[3];
     for (int a = 0; a < 3; ++a) binv[a] = bhi[a] > blo[a] ? 1.0f / (bhi[a] - blo[a]) : 0.0f;
-    sg->max_abs = 0.0f;
-    for (int a = 0; a < 3; ++a) sg->max_abs = std::max(sg->max_abs, std::max(fabsf(blo[a]), fabsf(bhi[a])));
-    sg->d.pad_abs = kScenePad * sg->max_abs;   // the scene-wide part of the triangle padding (bvh.cpp padded_box), for every kernel below that pads a triangle
 
-    // scratch: one arena per scene, kept for the next rebuild (about 330 B per triangle); a bump allocator over it
+    // scratch: one arena per scene, kept for the next rebuild (about 400 B per triangle); a bump allocator over it
     size_t sort_bytes = 0, scan_bytes = 0;
     hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 30, s);
     hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, s);
-    const size_t need = (size_t)n * 336u + std::max(sort_bytes, scan_bytes) + 64u * 256u;
+    const size_t need = (size_t)n * 400u + std::max(sort_bytes, scan_bytes) + 64u * 256u;
     if (sg->arena_bytes < need) {
         if (sg->arena) hipFree(sg->arena);
         sg->arena = nullptr; sg->arena_bytes = 0;
@@ -387,12 +395,12 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
     hipLaunchKernelGGL(k_lbvh_fit, dim3(b256), dim3(256), 0, s, T);
 
     // wide tree, level by level
-    SCR(uint4, nodes_big, 5u * (size_t)n)           // <= n-1 wide nodes
+    SCR(uint4, nodes_big, 4u * (size_t)n)           // <= n-1 wide nodes
+    SCR(uint32_t, leaf_big, (size_t)kNodeTris * n)  // their triangle places (16 per node; the final array is cut to the nodes there are)
     SCR(int, items_a, n) SCR(int, items_b, n) SCR(int, kid_ref, 8u * (size_t)n)
     SCR(uint32_t, inner_count, n) SCR(uint32_t, tri_count, n) SCR(uint32_t, inner_off, n) SCR(uint32_t, tri_off, n)
-    void *leaf_prim = nullptr, *tri_slot = nullptr;
-    LB_TRY(hipMalloc(&leaf_prim, sizeof(uint32_t) * n));
-    sg->leaf_prim = leaf_prim;
+    void *tri_slot = nullptr;
+    LB_TRY(hipMemsetAsync(leaf_big, 0xFF, sizeof(uint32_t) * (size_t)kNodeTris * n, s));   // holes: LPT_INVALID_INDEX
     LB_TRY(hipMalloc(&tri_slot, sizeof(uint32_t) * n));
     sg->tri_slot = tri_slot;
     LB_TRY(hipMemsetAsync(items_a, 0, sizeof(int), s));  // level 0 = the binary root
@@ -416,7 +424,7 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
         const uint32_t inner_total = tail[0] + tail[1], tri_total = tail[2] + tail[3];
         if ((size_t)level_first + n_items + inner_total > n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: node budget exceeded"));
         hipLaunchKernelGGL(k_lbvh_emit, dim3(div_up(n_items, 64u)), dim3(64), 0, s, T, L, inner_off, tri_off, level_first, level_first + n_items, tri_running,
-                           nodes_big, (uint32_t *)leaf_prim, (uint32_t *)tri_slot, items_next);
+                           nodes_big, leaf_big, (uint32_t *)tri_slot, items_next);
         sg->level_start.push_back(level_first);
         level_first += n_items;
         tri_running += tri_total;
@@ -430,8 +438,11 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
     LB_TRY(hipMemcpyAsync(sg->nodes, nodes_big, sizeof(Node8) * (size_t)n_nodes, hipMemcpyDeviceToDevice, s));
     LB_TRY(hipMalloc(&sg->node_lo, sizeof(float4) * (size_t)n_nodes));
     LB_TRY(hipMalloc(&sg->node_hi, sizeof(float4) * (size_t)n_nodes));
-    // Woop maps: prim order (host, double precision) -> leaf order
-    LB_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)n));
+    LB_TRY(hipMalloc(&sg->leaf_prim, sizeof(uint32_t) * (size_t)kNodeTris * n_nodes));
+    LB_TRY(hipMemcpyAsync(sg->leaf_prim, leaf_big, sizeof(uint32_t) * (size_t)kNodeTris * n_nodes, hipMemcpyDeviceToDevice, s));
+    // Woop maps: prim order (host, double precision) -> their places (holes stay zero)
+    LB_TRY(hipMalloc(&sg->woop, sizeof(WoopTri) * (size_t)kNodeTris * n_nodes));
+    LB_TRY(hipMemsetAsync(sg->woop, 0, sizeof(WoopTri) * (size_t)kNodeTris * n_nodes, s));
     const float4 *woop_src = dev_woop;
     if (host_woop) {
         SCR(float4, woop_prim, 3u * (size_t)n)
@@ -717,9 +728,9 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     }
     UP(srgb_lut, lut)
     if (!gpu_build) {
-        std::vector<uint32_t> tri_slot(acc.leaf_prim.size(), 0u);
-        if (!acc.tri_material.empty())
-            for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
+        std::vector<uint32_t> tri_slot(std::max<size_t>(acc.tri_material.size(), 1u), 0u);
+        for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot)
+            if (acc.leaf_prim[slot] != LPT_INVALID_INDEX) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
         UP(tri_slot, tri_slot)
         std::vector<float4> boxes(acc.nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));  // filled by the first refit
         UP(node_lo, boxes)
@@ -741,6 +752,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     d.stack_entries = acc.max_depth > 2u ? acc.max_depth - 1u : 1u;
     sg->max_abs = acc.max_abs;      // 0 on the GPU-build path: build_lbvh sets it from its bounds pass
     d.pad_abs = kScenePad * acc.max_abs;
+    for (int a = 0; a < 3; ++a) { d.grid_lo[a] = acc.grid_lo[a]; d.grid_step[a] = acc.grid_step[a]; }   // (the GPU-build path: build_lbvh sets its own)
     d.woop = (const float4 *)sg->woop;
     d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     d.tri_verts = (const float4 *)sg->tri_verts;
@@ -847,24 +859,16 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         }
     }
     if (changed && sg->stats.triangles) {
-        // the padding's scene-wide part follows the scene's largest coordinate: a scene that GREW under the edit (the root box after the refit says so) is refitted
-        // once more with the larger pad; it never shrinks (a pad a little too wide costs nothing)
-        for (int pass = 0; pass < 2; ++pass) {
-            for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
-                const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
-                if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
-            }
-            HIP_TRY(hipGetLastError());
-            float root[8];
-            HIP_TRY(hipMemcpyAsync(root, sg->node_lo, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(root + 4, sg->node_hi, sizeof(float) * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            float now_abs = 0.0f;
-            for (int a = 0; a < 3; ++a) now_abs = std::max(now_abs, std::max(fabsf(root[a]), fabsf(root[4 + a])));
-            if (!(now_abs > 1.25f * sg->max_abs)) break;
-            sg->max_abs = now_abs;
-            sg->d.pad_abs = kScenePad * now_abs;   // (renderers read sg->d at submission)
+        // the moved triangles' bounds first: the padding's scene-wide part follows the scene's largest coordinate (ANY growth counts — ADVICE r05 —; it never shrinks) and
+        // the node origins sit on a grid over the scene — both are inputs of the refit, which then runs once
+        float blo[3], bhi[3];
+        { const int bst = scene_bounds_and_grid(sg, sg->stats.triangles, s, blo, bhi, true); if (bst != LPT_OK) return bst; }
+        for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
+            const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];
+            if (b > a) hipLaunchKernelGGL(k_refit_level, dim3(div_up(b - a, 64u)), dim3(64), 0, s, sg->d, (uint4 *)sg->nodes, (float4 *)sg->node_lo, (float4 *)sg->node_hi, a, b);
         }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
     }
     if (out_rebaked) *out_rebaked = changed;
     return LPT_OK;
@@ -919,6 +923,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
         // the shading records were re-baked in place: put the old tree back in step with them (new Woop maps into the
         // old leaf order, boxes refitted; topology kept)
         hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(n, 256u)), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, n);
+        if (sg->stats.triangles) { float blo[3], bhi[3]; scene_bounds_and_grid(sg, n, s, blo, bhi, true); }   // (build_lbvh had set the NEW scene's grid in sg->d before old_d came back)
         if (sg->stats.triangles)
             for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
                 const uint32_t a = sg->level_start[l], b = sg->level_start[l + 1];

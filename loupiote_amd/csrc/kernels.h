@@ -20,14 +20,47 @@ constexpr int kMaxBounces = 64;
 constexpr int kBlock = 256;
 constexpr int kTraceBlock = 64;  // traversal kernels: one wave per block, so LDS / slots free up per wave
 
-// 80 B compressed 8-wide node, mirrors lpt::Node8 (common.h); read as five 16-byte loads
+// 64 B compressed 8-wide node, mirrors lpt::Node8 (common.h); read as FOUR 16-byte loads
 struct DNode8 {
-    uint4 n0;  // px, py, pz (float bits), ex | ey<<8 | ez<<16 | imask<<24
-    uint4 n1;  // child_base, tri_base, meta[0..3], meta[4..7]
+    uint4 n0;  // ox | oy << 16, oz | ex << 16 | ey << 24, ez | imask << 8 | leaf1 << 16 | leaf2 << 24, child_base
     uint4 n2;  // qlo_x[0..3], qlo_x[4..7], qlo_y[0..3], qlo_y[4..7]
     uint4 n3;  // qlo_z[0..3], qlo_z[4..7], qhi_x[0..3], qhi_x[4..7]
     uint4 n4;  // qhi_y[0..3], qhi_y[4..7], qhi_z[0..3], qhi_z[4..7]
 };
+using lpt::kNodeTris;   // triangle places per node (common.h): node i's leaf slot s keeps its one or two triangles at 16 i + 2 s + k
+
+// The node's header words.  The origin is a point of the scene grid (DScene::grid_*): ONE fp32 fma per axis, the same expression in every builder and consumer.
+__device__ __forceinline__ uint32_t node_imask(const uint4 &n0) { return (n0.z >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t node_leaves(const uint4 &n0) { return n0.z >> 16; }   // V = leaf1 | leaf2 << 8: bit s = slot s is a leaf child, bit 8 + s = ... with two triangles
+__device__ __forceinline__ uint32_t leaf_count(uint32_t V, uint32_t slot) { return 1u + ((V >> (8u + slot)) & 1u); }
+struct NodeGrid { float px, py, pz, sx, sy, sz; };   // origin and quantisation steps (powers of two) of a node
+template <typename Scene>
+__device__ __forceinline__ NodeGrid node_grid(const Scene &sc, const uint4 &n0) {
+    NodeGrid g;
+    g.px = fmaf((float)(n0.x & 0xFFFFu), sc.grid_step[0], sc.grid_lo[0]);
+    g.py = fmaf((float)(n0.x >> 16), sc.grid_step[1], sc.grid_lo[1]);
+    g.pz = fmaf((float)(n0.y & 0xFFFFu), sc.grid_step[2], sc.grid_lo[2]);
+    g.sx = __uint_as_float((n0.y << 7) & 0x7F800000u);
+    g.sy = __uint_as_float((n0.y >> 1) & 0x7F800000u);
+    g.sz = __uint_as_float((n0.z << 23) & 0x7F800000u);
+    return g;
+}
+// A TRIANGLE GROUP (16 * node, T): T = the triangles of one node that a ray still has to test — bit s = the first, bit 8 + s = the second triangle of leaf slot s;
+// their places are fixed: 16 * node + 2 * s + k.  (Places packed slot after slot inside a node's block — the index by popcount over the leaf masks carried in the
+// group's upper half — measured 2.6 % slower: the pop is on every triangle's path, profiles/r06_experiments_ab.txt D.)
+__device__ __forceinline__ uint32_t tg_index(uint32_t base, uint32_t bit) { return base + 2u * (bit & 7u) + (bit >> 3); }
+__device__ __forceinline__ uint32_t tg_pop(uint2 &tg) {   // takes the next triangle out of a non-empty group
+    const uint32_t bit = (uint32_t)__ffs((int)tg.y) - 1u;
+    tg.y &= tg.y - 1u;
+    return tg_index(tg.x, bit);
+}
+// bit s of an 8-bit mask -> bit s ^ o (o = 0..7): three conditional delta swaps
+__device__ __forceinline__ uint32_t xor_permute8(uint32_t x, uint32_t o) {
+    uint32_t t = ((x >> 1) ^ x) & ((o & 1u) ? 0x55u : 0u); x ^= t | (t << 1);
+    t = ((x >> 2) ^ x) & ((o & 2u) ? 0x33u : 0u); x ^= t | (t << 2);
+    t = ((x >> 4) ^ x) & ((o & 4u) ? 0x0Fu : 0u); x ^= t | (t << 4);
+    return x;
+}
 
 struct DImage { uint32_t offset, width, height, pad; };  // pad = 8x4-texel tiles per row (texels are tiled, device.hip)
 constexpr uint32_t kTriRec = 8;
@@ -53,6 +86,7 @@ struct DScene {
     const uint2 *pair_texels;
     const DImage *pair_images;   // offset in 8-byte texels, pad = tiles per row (ceil(width / 3))
     uint32_t n_tris, n_materials, n_lights, n_images, n_pairs;
+    float grid_lo[3], grid_step[3];   // the scene grid of the node origins (common.h scene_grid): origin = grid_lo + o * grid_step
     float pad_abs;               // the scene-wide part of the triangle padding (refit / LBVH; bvh.cpp padded_box): kScenePad x the scene's largest |coordinate|
 };
 constexpr uint32_t kPairedBit = 0x40000000u;
@@ -366,7 +400,7 @@ __device__ __forceinline__ float safe_inv(float d) {
 // Karras & Laine, HPG 2017).  ANY: stop at the first hit in (0, tmax].
 //
 //  * a "node group" (base index, hit bits << 24 | imask) names the still-unvisited inner
-//    children of one node; a "triangle group" (tri base, 24 hit bits) its hit triangles.
+//    children of one node; a "triangle group" (16 * node, 16 hit bits: tg_pop above) its hit triangles.
 //    One 8-byte stack entry per tree level, kept in LDS (`stack` = this lane's column,
 //    stride kTraceBlock entries).
 //  * child boxes are decoded on the fly: t = q * (2^e / d) + (p - o) / d, near / far byte
@@ -398,46 +432,46 @@ __device__ __forceinline__ void ray_begin(RayState &rs, f3 o, f3 d, float tmax) 
     rs.sp = 0;
 }
 
-// The node visit of a step: takes the next member out of the current node group rs.ng (which must have one), pushes what is left
-// of the group, fetches the node and tests its eight children.  rs.ng = the node's hit inner children; returns its hit triangles.
+// The node visit of a step, in two halves so that a step can put other work between the fetch and the test (ray_step_pipe).
+// node_fetch: takes the next member out of the current node group rs.ng (which must have one), pushes what is left of the group and fetches the node's four rows.
+// node_test: tests the eight children against the ray's CURRENT best hit; rs.ng = the node's hit inner children; returns its hit triangles.
+struct NodeRows { uint4 n0, n2, n3, n4; uint32_t index; };
 template <bool STATS>
-__device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint2 *stack, uint32_t &n_nodes) {
+__device__ __forceinline__ void node_fetch(const DScene &sc, RayState &rs, uint2 *stack, uint32_t &n_nodes, NodeRows &nr) {
+    const uint32_t hits = rs.ng.y;
+    const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
+    rs.ng.y &= ~(1u << bit);
+    if (rs.ng.y & 0xFF000000u) { stack[rs.sp * kTraceBlock] = rs.ng; rs.sp++; }
+    const uint32_t slot = (bit - 24u) ^ rs.oinv;
+    const uint32_t rel = (uint32_t)__popc(hits & ~(0xFFFFFFFFu << slot));  // inner children before `slot`
+    nr.index = rs.ng.x + rel;
+    const DNode8 *n = sc.nodes + nr.index;
+    nr.n0 = n->n0; nr.n2 = n->n2; nr.n3 = n->n3; nr.n4 = n->n4;
+    if (STATS) n_nodes++;
+}
+__device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const NodeRows &nr) {
     {
-        const uint32_t hits = rs.ng.y;
-        const uint32_t bit = 31u - (uint32_t)__clz((int)hits);
-        rs.ng.y &= ~(1u << bit);
-        if (rs.ng.y & 0xFF000000u) { stack[rs.sp * kTraceBlock] = rs.ng; rs.sp++; }
-        const uint32_t slot = (bit - 24u) ^ rs.oinv;
-        const uint32_t rel = (uint32_t)__popc(hits & ~(0xFFFFFFFFu << slot));  // inner children before `slot`
-        const DNode8 *n = sc.nodes + (rs.ng.x + rel);
-        const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
-        if (STATS) n_nodes++;
+        const uint4 n0 = nr.n0, n2 = nr.n2, n3 = nr.n3, n4 = nr.n4;
+        const uint32_t node_index = nr.index;
+        const NodeGrid g = node_grid(sc, n0);
         const bool negx = rs.ix < 0.0f, negy = rs.iy < 0.0f, negz = rs.iz < 0.0f;
-        const uint32_t oinv4 = rs.oinv * 0x01010101u;   // (this and the other two v_mul_lo_u32 of a visit as shifts / sub: no change, profiles/r05_experiments_ab.txt E)
         // t(q) = q * a + b per axis; a is exact (power-of-two step times 1/d), b carries three roundings.
         // |error of the computed t| <= 2^-24 * (4|b| + 510|a|), so widening b by eps = 2^-21 * (|b| + 255|a|)
         // towards the outside on both ends keeps the test conservative wherever the ray starts.
         const float kEps = 4.76837158203125e-7f;  // 2^-21
-        const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * rs.ix;
-        const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * rs.iy;
-        const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * rs.iz;
-        const float bx = (__uint_as_float(n0.x) - rs.o.x) * rs.ix;
-        const float by = (__uint_as_float(n0.y) - rs.o.y) * rs.iy;
-        const float bz = (__uint_as_float(n0.z) - rs.o.z) * rs.iz;
+        const float ax = g.sx * rs.ix, ay = g.sy * rs.iy, az = g.sz * rs.iz;
+        const float bx = (g.px - rs.o.x) * rs.ix;
+        const float by = (g.py - rs.o.y) * rs.iy;
+        const float bz = (g.pz - rs.o.z) * rs.iz;
         const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
         const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
         const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
         const float bnx = bx - ex, bny = by - ey, bnz = bz - ez;
         const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez;
         const float tbest = rs.best.t;
-        uint32_t hitmask = 0u;
+        uint32_t h = 0u;   // bit s: the ray's interval meets slot s's box
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const uint32_t meta4 = half ? n1.w : n1.z;
-            const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-            const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xFFu;
-            const uint32_t bit_index4 = (meta4 ^ (oinv4 & inner_mask4)) & 0x1F1F1F1Fu;
-            const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
             const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
             const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
             const uint32_t qnx = negx ? hix : lox, qfx = negx ? lox : hix;
@@ -454,11 +488,13 @@ __device__ __forceinline__ uint2 node_visit(const DScene &sc, RayState &rs, uint
                 const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), az, bfz);
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
-                if (tn <= tf) hitmask |= ((child_bits4 >> sh) & 0xFFu) << ((bit_index4 >> sh) & 0xFFu);
+                if (tn <= tf) h |= 1u << (4 * half + j);
             }
         }
-        rs.ng = make_uint2(n1.x, (hitmask & 0xFF000000u) | (n0.w >> 24));
-        return make_uint2(n1.y, hitmask & 0x00FFFFFFu);
+        // empty slots have inverted boxes; should the widening ever let one pass, it is in neither mask below
+        const uint32_t imask = node_imask(n0), V = node_leaves(n0);
+        rs.ng = make_uint2(n0.w, (xor_permute8(h & imask, rs.oinv) << 24) | imask);
+        return make_uint2(node_index * kNodeTris, (h | (h << 8)) & V);
     }
 }
 
@@ -471,12 +507,12 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
             rs.sp--;
             rs.ng = stack[rs.sp * kTraceBlock];
         }
-        rs.tg = node_visit<STATS>(sc, rs, stack, n_nodes);
+        NodeRows nr;
+        node_fetch<STATS>(sc, rs, stack, n_nodes, nr);
+        rs.tg = node_test(sc, rs, nr);
     }
-    if (rs.tg.y) {
-        const uint32_t k = (uint32_t)__ffs((int)rs.tg.y) - 1u;
-        rs.tg.y &= rs.tg.y - 1u;
-        const uint32_t ti = rs.tg.x + k;
+    if (rs.tg.y != 0u) {
+        const uint32_t ti = tg_pop(rs.tg);
         const float4 *w = sc.woop + 3u * (size_t)ti;
         const float4 r0 = w[0], r1 = w[1], r2 = w[2];
         if (STATS) n_tris++;
@@ -502,26 +538,27 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
 template <bool STATS>
 __device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris) {
     const bool node_work = (rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0;
-    const bool tri_work = rs.tg.y != 0u;           // rs.tg2 is only ever occupied while rs.tg is
+    const bool tri_work = (rs.tg.y != 0u);      // rs.tg2 is only ever occupied while rs.tg is
     if (!node_work && !tri_work) return true;
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
     uint32_t ti = 0;
     if (tri_work) {
-        const uint32_t k = (uint32_t)__ffs((int)rs.tg.y) - 1u;
-        rs.tg.y &= rs.tg.y - 1u;
-        ti = rs.tg.x + k;
+        ti = tg_pop(rs.tg);
         const float4 *w = sc.woop + 3u * (size_t)ti;
         r0 = w[0]; r1 = w[1]; r2 = w[2];
         if (STATS) n_tris++;
     }
-    uint2 found = make_uint2(0u, 0u);
-    if (node_work && rs.tg2.y == 0u) {
+    const bool visit = node_work && (rs.tg2.y == 0u);
+    NodeRows nr;
+    if (visit) {
         if (!(rs.ng.y & 0xFF000000u)) {
             rs.sp--;
             rs.ng = stack[rs.sp * kTraceBlock];
         }
-        found = node_visit<STATS>(sc, rs, stack, n_nodes);
+        node_fetch<STATS>(sc, rs, stack, n_nodes, nr);
     }
+    // the triangle FIRST (round 6): its rows were requested first and arrive first, a hit shrinks the interval the children below are tested against (fewer of them pass),
+    // and its twelve row registers are dead before the child tests — the step's register peak — begin
     if (tri_work) {
         float t, u, v;
         if (ray_triangle(r0, r1, r2, rs.o, rs.d, rs.best.t, t, u, v)) {
@@ -531,8 +568,10 @@ __device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, ui
             if (ANY) return true;
         }
     }
+    uint2 found = make_uint2(0u, 0u);
+    if (visit) found = node_test(sc, rs, nr);
     if (rs.tg.y == 0u) { rs.tg = rs.tg2; rs.tg2.y = 0u; }
-    if (found.y) { if (rs.tg.y == 0u) rs.tg = found; else rs.tg2 = found; }
+    if (found.y != 0u) { if (rs.tg.y == 0u) rs.tg = found; else rs.tg2 = found; }
     return false;
 }
 
@@ -677,14 +716,13 @@ __device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3
         uint32_t child = 0u, first = 0u, bits = 0u;
         if (work) {
             const DNode8 *n = sc.nodes + node;
-            const uint4 n0 = n->n0, n1 = n->n1, n2 = n->n2, n3 = n->n3, n4 = n->n4;
+            const uint4 n0 = n->n0, n2 = n->n2, n3 = n->n3, n4 = n->n4;
             const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
-            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
-            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
-            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
-            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
-            const float by = (__uint_as_float(n0.y) - o.y) * iy;
-            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+            const NodeGrid g = node_grid(sc, n0);
+            const float ax = g.sx * ix, ay = g.sy * iy, az = g.sz * iz;
+            const float bx = (g.px - o.x) * ix;
+            const float by = (g.py - o.y) * iy;
+            const float bz = (g.pz - o.z) * iz;
             const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
             const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
             const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
@@ -697,28 +735,25 @@ __device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3
             const float tnz = fmaf((float)(negz ? hiz : loz), az, bz - ez), tfz = fmaf((float)(negz ? loz : hiz), az, bz + ez);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-            const uint32_t imask = n0.w >> 24;
-            const uint32_t meta = ((hi4 ? n1.w : n1.z) >> sh) & 0xFFu;
-            const bool inner = ((imask >> c) & 1u) != 0u;
-            const bool hit = tn <= tf && meta != 0u;     // empty slots: meta 0 (their boxes are inverted as well)
-            hit_inner = hit && inner;
-            hit_leaf = hit && !inner;
-            child = n1.x + (uint32_t)__popc(imask & ~(0xFFFFFFFFu << c));
-            first = n1.y + (meta & 31u);
-            bits = meta >> 5;
+            const uint32_t imask = node_imask(n0), V = node_leaves(n0);
+            const bool hit = tn <= tf;     // empty slots (inverted boxes) are in neither mask
+            hit_inner = hit && ((imask >> c) & 1u) != 0u;
+            hit_leaf = hit && ((V >> c) & 1u) != 0u;
+            child = n0.w + (uint32_t)__popc(imask & ~(0xFFFFFFFFu << c));
+            first = node * kNodeTris + 2u * c;
+            bits = leaf_count(V, c);
         }
         if (STATS) n_nodes += m;
         // inner children: appended to the stack (ballot + prefix count)
         const unsigned long long im = __ballot(hit_inner);
         if (hit_inner) stk[count + (uint32_t)__popcll(im & ((1ull << lane) - 1ull))] = child;
         count += (uint32_t)__popcll(im);
-        // leaf children: the lane tests its (up to three) triangles against the round's best
+        // leaf children: the lane tests its (one or two) triangles against the round's best
         float ct = 0.f, cu = 0.f, cv = 0.f;
         uint32_t cprim = 0xFFFFFFFFu;
         bool cand = false;
         if (hit_leaf) {
-            for (uint32_t k = 0; k < 3u; ++k) {
-                if (!((bits >> k) & 1u)) continue;
+            for (uint32_t k = 0; k < bits; ++k) {
                 const uint32_t ti = first + k;
                 const float4 *w = sc.woop + 3u * (size_t)ti;
                 const float4 r0 = w[0], r1 = w[1], r2 = w[2];
@@ -763,20 +798,17 @@ __device__ __forceinline__ uint32_t tail_park(const RayState &rs, const unsigned
     }
     return (uint32_t)__popcll(live);
 }
-// the wave's part: a function of its own (not inlined), so that its registers are allocated apart from the traversal loop's — inlined, the loop above it spills
-struct TailArgs { const DNode8 *nodes; const float4 *woop; const uint32_t *leaf_prim; const lpt_light *lights; uint32_t n_lights, stack_entries, n_live; float4 *hits; const float4 *sq_c; float4 *Lsum; };
-__device__ __forceinline__ void tail_walk(const TailArgs a) {
+// the wave's part, behind the traversal loop (its registers are not the loop's)
+__device__ __forceinline__ void tail_walk(const DScene &sc, const uint32_t n_live, float4 *hits, const float4 *sq_c, float4 *Lsum) {
     static_assert(kTraceBlock == 64, "one wave per block: the cooperative stack is the wave's");
-    DScene sc = {};
-    sc.nodes = a.nodes; sc.woop = a.woop; sc.leaf_prim = a.leaf_prim; sc.lights = a.lights; sc.n_lights = a.n_lights;
     uint32_t lane = threadIdx.x;
     asm volatile("" : "+v"(lane));   // as in tail_park
     const uint2 *columns = reinterpret_cast<const uint2 *>(lds_dyn);
-    uint32_t *tail_lds = reinterpret_cast<uint32_t *>(lds_dyn + a.stack_entries * kTraceBlock * sizeof(uint2));
+    uint32_t *tail_lds = reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2));
     const uint4 *state = reinterpret_cast<const uint4 *>(tail_lds);
     uint32_t *stk = tail_lds + kTailMax * kTailStateWords;
     __syncthreads();
-    for (uint32_t r = 0; r < a.n_live; ++r) {
+    for (uint32_t r = 0; r < n_live; ++r) {
         const uint4 s0 = state[5u * r], s1 = state[5u * r + 1u], s2 = state[5u * r + 2u], s3 = state[5u * r + 3u], s4 = state[5u * r + 4u];
         const f3 o = mk3(__uint_as_float(s0.x), __uint_as_float(s0.y), __uint_as_float(s0.z)), d = mk3(__uint_as_float(s0.w), __uint_as_float(s1.x), __uint_as_float(s1.y));
         const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);          // as ray_begin
@@ -803,17 +835,17 @@ __device__ __forceinline__ void tail_walk(const TailArgs a) {
             if (has) stk[count + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = node;
             count += (uint32_t)__popcll(hm);
         }
-        // the triangles the lane had found and not yet tested: lanes 0..23 the group in work, 24..47 the one waiting behind it (one-round-trip step)
+        // the triangles the lane had found and not yet tested: lanes 0..15 the group in work, 16..31 the one waiting behind it (one-round-trip step)
         bool done = false;
         {
-            const uint32_t k = lane < 24u ? lane : lane - 24u;
-            const uint2 g = lane < 24u ? make_uint2(s3.x, s3.y) : make_uint2(s3.z, s3.w);
-            const bool mine = lane < 48u && ((g.y >> k) & 1u) != 0u;
+            const uint32_t k = lane & 15u;
+            const uint2 g = lane < 16u ? make_uint2(s3.x, s3.y) : make_uint2(s3.z, s3.w);
+            const bool mine = lane < 32u && ((g.y >> k) & 1u) != 0u;
             float ct = 0.f, cu = 0.f, cv = 0.f;
             uint32_t cprim = 0xFFFFFFFFu;
             bool cand = false;
             if (mine) {
-                const uint32_t ti = g.x + k;
+                const uint32_t ti = tg_index(g.x, k);
                 const float4 *w = sc.woop + 3u * (size_t)ti;
                 const float4 r0 = w[0], r1 = w[1], r2 = w[2];
                 if (ray_triangle(r0, r1, r2, o, d, best.t, ct, cu, cv)) { cprim = sc.leaf_prim[ti]; cand = true; }
@@ -828,14 +860,14 @@ __device__ __forceinline__ void tail_walk(const TailArgs a) {
         if (!done) coop_walk<false>(sc, o, d, ix, iy, iz, shadow, best, stk, count, kTailStack, lane, nn, nt);
         if (shadow) {
             if (lane == 0 && best.prim == 0xFFFFFFFFu) {   // unoccluded: deposit the light sample
-                const float4 cc = a.sq_c[ray];
-                float4 Lp = a.Lsum[slot_bits];
+                const float4 cc = sq_c[ray];
+                float4 Lp = Lsum[slot_bits];
                 Lp.x = Lp.x + cc.x; Lp.y = Lp.y + cc.y; Lp.z = Lp.z + cc.z;
-                a.Lsum[slot_bits] = Lp;
+                Lsum[slot_bits] = Lp;
             }
         } else {
             intersect_lights(sc, o, d, best);
-            if (lane == 0) st_nt(a.hits + ray, make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)));
+            if (lane == 0) st_nt(hits + ray, make_float4(best.t, best.u, best.v, __uint_as_float(best.prim)));
         }
         __syncthreads();            // the column is reused by the next ray
     }
@@ -862,6 +894,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
+    uint32_t tail_live = 0u;   // TAIL: rays parked for the cooperative walk behind the loop
     for (;;) {
         const unsigned long long amask = __ballot(active);
         const int n_active = __popcll(amask);
@@ -922,10 +955,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             } else if (n_active == 0) break;
             else if (TAIL && n_active <= (int)tail) {
                 // both queues are dry and few rays are left: the wave finishes them cooperatively, in place (tail_park / tail_walk; the host sets `tail` only without the stats)
-                TailArgs ta = {sc.nodes, sc.woop, sc.leaf_prim, sc.lights, sc.n_lights, sc.stack_entries, 0u, hits, sq.c, Lsum};
-                ta.n_live = tail_park<PIPE>(rs, amask, active, shadow, ray, reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2)));
-                if (lane == 0) atomicAdd(&ctr->tail_rays, ta.n_live);
-                tail_walk(ta);
+                tail_live = tail_park<PIPE>(rs, amask, active, shadow, ray, reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2)));
                 break;
             }
         }
@@ -933,7 +963,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
         if (STATS) {
             w_steps++;
             w_live += (uint32_t)__popcll(__ballot(active));
-            w_node += (uint32_t)__popcll(__ballot(PIPE ? active && rs.tg2.y == 0u && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0) : active && rs.tg.y == 0u));
+            w_node += (uint32_t)__popcll(__ballot(PIPE ? active && (rs.tg2.y == 0u) && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0) : active && (rs.tg.y == 0u)));
         }
         if ((STATS || budget) && active) my_steps++;
         if (active && (PIPE ? ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt) : ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt))) {
@@ -952,6 +982,10 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             w_tri += (uint32_t)__popcll(__ballot(dt != 0u));
             if (shadow) { s_nodes += dn; s_tris += dt; } else { n_nodes += dn; n_tris += dt; }
         }
+    }
+    if (TAIL && tail_live) {
+        if (lane == 0) atomicAdd(&ctr->tail_rays, tail_live);
+        tail_walk(sc, tail_live, hits, sq.c, Lsum);
     }
     if (STATS) {
         atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
@@ -1025,12 +1059,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_coop(DScene sc, Queue q, 
 // five / three consecutive 16-byte scalar loads from a wave-uniform address (the compiler keeps uniform loads of memory it cannot
 // prove unwritten on the vector path: 64 lanes fetching one address)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// the node's header (origin, exponents, imask; child / triangle base, meta bytes): the 48 plane bytes behind it reach the lanes through LDS
-__device__ __forceinline__ void sload_node_header(const void *p, uint4 &a, uint4 &b) {
-    u32x4 va, vb;
-    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(va), "=&s"(vb) : "s"(p) : "memory");
-    a = make_uint4(va.x, va.y, va.z, va.w); b = make_uint4(vb.x, vb.y, vb.z, vb.w);
+// the node's header (grid origin, exponents, masks, child base): the 48 plane bytes behind it reach the lanes through LDS
+__device__ __forceinline__ void sload_node_header(const void *p, uint4 &a) {
+    u32x4 va;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(va) : "s"(p) : "memory");
+    a = make_uint4(va.x, va.y, va.z, va.w);
 }
 __device__ __forceinline__ void sload_tri(const void *p, float4 &a, float4 &b, float4 &c) {
     u32x4 va, vb, vc;
@@ -1124,20 +1157,19 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8))
             // the 48 quantised planes are the same for every lane: lane j fetches and converts plane j — ONE conversion instruction for the wave
             // instead of 48 — and LDS hands each lane the ones it needs (its near and far plane per axis, four children per read).  The fetch is issued
             // BEFORE the header's scalar loads (which wait for themselves only): the two round trips overlap
-            const uint32_t plane_byte = reinterpret_cast<const uint8_t *>(nodes + node_index)[32u + (lane < 48u ? lane : lane - 48u)];   // every lane: no branch around the load
-            uint4 n0, n1;
-            sload_node_header(nodes + node_index, n0, n1);   // wave-uniform address
+            const uint32_t plane_byte = reinterpret_cast<const uint8_t *>(nodes + node_index)[16u + (lane < 48u ? lane : lane - 48u)];   // every lane: no branch around the load
+            uint4 n0;
+            sload_node_header(nodes + node_index, n0);   // wave-uniform address
             __syncthreads();   // the previous node's plane reads are done before its planes are overwritten (one wave: no wait, a compiler fence)
             if (lane < 48u) planes[lane] = (float)plane_byte;
             __syncthreads();
             if (STATS) visits++;
             const float kEps = 4.76837158203125e-7f;  // 2^-21, as in node_visit
-            const float ax = __uint_as_float((n0.w & 0xFFu) << 23) * ix;
-            const float ay = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23) * iy;
-            const float az = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23) * iz;
-            const float bx = (__uint_as_float(n0.x) - o.x) * ix;
-            const float by = (__uint_as_float(n0.y) - o.y) * iy;
-            const float bz = (__uint_as_float(n0.z) - o.z) * iz;
+            const NodeGrid g = node_grid(sc, n0);   // wave-uniform
+            const float ax = g.sx * ix, ay = g.sy * iy, az = g.sz * iz;
+            const float bx = (g.px - o.x) * ix;
+            const float by = (g.py - o.y) * iy;
+            const float bz = (g.pz - o.z) * iz;
             const float ex = fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kEps;
             const float ey = fmaf(fabsf(ay), 255.0f, fabsf(by)) * kEps;
             const float ez = fmaf(fabsf(az), 255.0f, fabsf(bz)) * kEps;
@@ -1148,8 +1180,8 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8))
             // On the bench frame 2.45 of a node's 8 children pass (1.24 are entered): the per-lane tests below run for those only
             uint32_t cand = 0xFFu;
             if (coherent) {
-                const float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
-                const float gx = __uint_as_float(n0.x) - o0x, gy = __uint_as_float(n0.y) - o0y, gz = __uint_as_float(n0.z) - o0z;
+                const float sx = g.sx, sy = g.sy, sz = g.sz;
+                const float gx = g.px - o0x, gy = g.py - o0y, gz = g.pz - o0z;
                 const float dnx = fmaf(planes[cnx], sx, gx), dfx = fmaf(planes[cfx], sx, gx);
                 const float dny = fmaf(planes[cny], sy, gy), dfy = fmaf(planes[cfy], sy, gy);
                 const float dnz = fmaf(planes[cnz], sz, gz), dfz = fmaf(planes[cfz], sz, gz);
@@ -1171,17 +1203,15 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8))
                 if (__ballot(tn <= tf) != 0ull) entered |= 1u << j;
             }
             // empty slots have inverted boxes (lo 255, hi 0) and are never entered
-            const uint32_t imask = n0.w >> 24;
+            const uint32_t imask = node_imask(n0);
             // leaves first: every lane tests every triangle of an entered leaf slot
-            uint32_t leaves = entered & ~imask;
+            const uint32_t V = node_leaves(n0);
+            uint32_t leaves = entered & V & 0xFFu;
             while (leaves) {
                 const uint32_t sl = (uint32_t)__ffs((int)leaves) - 1u;
                 leaves &= leaves - 1u;
-                const uint32_t meta = ((sl < 4u ? n1.z : n1.w) >> (8u * (sl & 3u))) & 0xFFu;
-                uint32_t bits = meta >> 5;
-                const uint32_t first = n1.y + (meta & 31u);
-                for (uint32_t k = 0; bits; ++k, bits >>= 1) {
-                    if (!(bits & 1u)) continue;
+                const uint32_t first = node_index * kNodeTris + 2u * sl, cnt = leaf_count(V, sl);
+                for (uint32_t k = 0; k < cnt; ++k) {
                     const uint32_t ti = first + k;
                     float4 r0, r1, r2;
                     sload_tri(woop + 3u * (size_t)ti, r0, r1, r2);
@@ -1207,7 +1237,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8))
             for (uint32_t m = keyed; m; m &= m - 1u) {   // ascending key: the largest key is pushed last and pops first
                 const uint32_t sl = ((uint32_t)__ffs((int)m) - 1u) ^ oinv;
                 const uint32_t rel = (uint32_t)__popc(imask & ~(0xFFFFFFFFu << sl));
-                if (lane == 0) stk[sp] = n1.x + rel;
+                if (lane == 0) stk[sp] = n0.w + rel;
                 sp++;
             }
             have = sp > 0;
@@ -1751,7 +1781,7 @@ __global__ __launch_bounds__(kTraceBlock) LPT_PATH_ATTR void k_path(DScene sc, D
         if (STATS) {
             w_steps++;
             w_live += (uint32_t)__popcll(__ballot(phase == 1u));
-            w_node += (uint32_t)__popcll(__ballot(phase == 1u && rs.tg2.y == 0u && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0)));
+            w_node += (uint32_t)__popcll(__ballot(phase == 1u && (rs.tg2.y == 0u) && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0)));
         }
         if (phase == 1u && ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt)) {
             if (shadow) {
@@ -2118,24 +2148,23 @@ __device__ __forceinline__ void refit_grow_tri(const DScene &sc, uint32_t prim, 
 __global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, float4 *node_lo, float4 *node_hi, uint32_t first, uint32_t last) {
     const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= last) return;
-    uint4 *nw = nodes_rw + 5u * (size_t)i;
-    const uint4 n0 = nw[0], n1 = nw[1];
-    const uint32_t imask = n0.w >> 24;
+    uint4 *nw = nodes_rw + 4u * (size_t)i;
+    const uint4 n0 = nw[0];
+    const uint32_t imask = node_imask(n0);
     float clo[8][3], chi[8][3];
     float nlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, nhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     uint32_t rel = 0;
     bool any = false;
+    const uint32_t V = node_leaves(n0);
     for (int sl = 0; sl < 8; ++sl) {
-        const uint32_t meta = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xFFu;
         for (int a = 0; a < 3; ++a) { clo[sl][a] = 3.0e38f; chi[sl][a] = -3.0e38f; }
         if ((imask >> sl) & 1u) {
-            const uint32_t c = n1.x + rel++;
+            const uint32_t c = n0.w + rel++;
             const float4 l = node_lo[c], h = node_hi[c];
             clo[sl][0] = l.x; clo[sl][1] = l.y; clo[sl][2] = l.z; chi[sl][0] = h.x; chi[sl][1] = h.y; chi[sl][2] = h.z;
-        } else if (meta) {
-            const uint32_t bits = meta >> 5, off = meta & 31u;
-            for (uint32_t k = 0; k < 3; ++k)
-                if ((bits >> k) & 1u) refit_grow_tri(sc, sc.leaf_prim[n1.y + off + k], clo[sl], chi[sl]);
+        } else if ((V >> sl) & 1u) {
+            const uint32_t cnt = leaf_count(V, (uint32_t)sl);
+            for (uint32_t k = 0; k < cnt; ++k) refit_grow_tri(sc, sc.leaf_prim[i * kNodeTris + 2u * (uint32_t)sl + k], clo[sl], chi[sl]);
         } else continue;
         any = true;
         for (int a = 0; a < 3; ++a) { nlo[a] = fminf(nlo[a], clo[sl][a]); nhi[a] = fmaxf(nhi[a], chi[sl][a]); }
@@ -2143,10 +2172,21 @@ __global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, 
     if (!any) return;  // the empty scene's single node
     node_lo[i] = make_float4(nlo[0], nlo[1], nlo[2], 0.f);
     node_hi[i] = make_float4(nhi[0], nhi[1], nhi[2], 0.f);
+    // the node's origin: the scene-grid point at or below its box minimum (common.h grid_snap); the steps cover the box from there
+    uint32_t og[3];
+    float org[3];
+    for (int a = 0; a < 3; ++a) {
+        double u = floor(((double)nlo[a] - (double)sc.grid_lo[a]) / (double)sc.grid_step[a]);
+        u = u < 0.0 ? 0.0 : (u > 65535.0 ? 65535.0 : u);
+        uint32_t ui = (uint32_t)u;
+        float p = fmaf((float)ui, sc.grid_step[a], sc.grid_lo[a]);
+        while (p > nlo[a] && ui > 0u) { --ui; p = fmaf((float)ui, sc.grid_step[a], sc.grid_lo[a]); }
+        og[a] = ui; org[a] = p;
+    }
     uint32_t eb[3];
     double scale[3];
     for (int a = 0; a < 3; ++a) {
-        const double ext = (double)nhi[a] - (double)nlo[a];
+        const double ext = (double)nhi[a] - (double)org[a];
         int e = -126;
         if (ext > 0.0) {
             int k;
@@ -2158,20 +2198,19 @@ __global__ __launch_bounds__(64) void k_refit_level(DScene sc, uint4 *nodes_rw, 
     }
     uint8_t q[6][8];
     for (int sl = 0; sl < 8; ++sl) {
-        const uint32_t meta = ((sl < 4 ? n1.z : n1.w) >> (8 * (sl & 3))) & 0xFFu;
-        if (!meta) { for (int a = 0; a < 3; ++a) { q[a][sl] = 255; q[3 + a][sl] = 0; } continue; }
+        if (!(((imask | V) >> sl) & 1u)) { for (int a = 0; a < 3; ++a) { q[a][sl] = 255; q[3 + a][sl] = 0; } continue; }
         for (int a = 0; a < 3; ++a) {
-            const double l = floor(((double)clo[sl][a] - (double)nlo[a]) / scale[a]);
-            const double h = ceil(((double)chi[sl][a] - (double)nlo[a]) / scale[a]);
+            const double l = floor(((double)clo[sl][a] - (double)org[a]) / scale[a]);
+            const double h = ceil(((double)chi[sl][a] - (double)org[a]) / scale[a]);
             q[a][sl] = (uint8_t)fmin(fmax(l, 0.0), 255.0);
             q[3 + a][sl] = (uint8_t)fmin(fmax(h, 0.0), 255.0);
         }
     }
     auto pack4 = [&](int plane, int h) { return (uint32_t)q[plane][4 * h] | ((uint32_t)q[plane][4 * h + 1] << 8) | ((uint32_t)q[plane][4 * h + 2] << 16) | ((uint32_t)q[plane][4 * h + 3] << 24); };
-    nw[0] = make_uint4(__float_as_uint(nlo[0]), __float_as_uint(nlo[1]), __float_as_uint(nlo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24));
-    nw[2] = make_uint4(pack4(0, 0), pack4(0, 1), pack4(1, 0), pack4(1, 1));
-    nw[3] = make_uint4(pack4(2, 0), pack4(2, 1), pack4(3, 0), pack4(3, 1));
-    nw[4] = make_uint4(pack4(4, 0), pack4(4, 1), pack4(5, 0), pack4(5, 1));
+    nw[0] = make_uint4(og[0] | (og[1] << 16), og[2] | (eb[0] << 16) | (eb[1] << 24), eb[2] | (n0.z & 0xFFFFFF00u), n0.w);   // masks and child base: the builder's
+    nw[1] = make_uint4(pack4(0, 0), pack4(0, 1), pack4(1, 0), pack4(1, 1));
+    nw[2] = make_uint4(pack4(2, 0), pack4(2, 1), pack4(3, 0), pack4(3, 1));
+    nw[3] = make_uint4(pack4(4, 0), pack4(4, 1), pack4(5, 0), pack4(5, 1));
 }
 
 // ------------------------------------------------------------------ device-side baking of ONE instance (SPEC §2.5, §6)

@@ -67,7 +67,7 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
         const Node8 &n = a.nodes[e.node];
         st.nodes++;
         const uint8_t ebytes[3] = {n.ex, n.ey, n.ez};
-        const float p[3] = {n.px, n.py, n.pz};
+        const float p[3] = {fmaf((float)n.ox, a.grid_step[0], a.grid_lo[0]), fmaf((float)n.oy, a.grid_step[1], a.grid_lo[1]), fmaf((float)n.oz, a.grid_step[2], a.grid_lo[2])};
         const uint8_t *qlo[3] = {n.qlox, n.qloy, n.qloz}, *qhi[3] = {n.qhix, n.qhiy, n.qhiz};
         float an[3], bn[3], af[3], bf[3];
         for (int k = 0; k < 3; ++k) {
@@ -84,11 +84,10 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
         int n_inner = 0;
         uint32_t rel = 0;
         for (int sl = 0; sl < 8; ++sl) {
-            const uint8_t meta = n.meta[sl];
-            const bool is_inner = (n.imask >> sl) & 1u;
+            const bool is_inner = (n.imask >> sl) & 1u, is_leaf = (n.leaf1 >> sl) & 1u;
             const uint32_t my_rel = rel;
             if (is_inner) rel++;
-            if (!meta) continue;
+            if (!is_inner && !is_leaf) continue;
             float tn = 0.0f, tf = best.t;
             for (int k = 0; k < 3; ++k) {
                 const bool neg = inv[k] < 0.0f;
@@ -99,9 +98,8 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
             if (!(tn <= tf)) continue;
             if (is_inner) inner[n_inner++] = {by_distance ? ~__builtin_bit_cast(uint32_t, tn) : ((uint32_t)sl ^ oinv), n.child_base + my_rel};
             else {
-                const uint32_t cnt_bits = meta >> 5, off = meta & 31u;
-                for (uint32_t k = 0; k < 3; ++k)
-                    if ((cnt_bits >> k) & 1u) { st.tris++; consider(a, n.tri_base + off + k, o, d, best); }
+                const uint32_t cnt = 1u + ((n.leaf2 >> sl) & 1u);
+                for (uint32_t k = 0; k < cnt; ++k) { st.tris++; consider(a, e.node * kNodeTris + 2u * (uint32_t)sl + k, o, d, best); }
             }
         }
         // push so that the largest key pops first
@@ -145,7 +143,7 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> seen(n_baked, 0);
     size_t bad_refs = 0;
     if (n_baked)
-        for (uint32_t p : acc.leaf_prim) { if (p >= n_baked || seen[p]++) bad_refs++; }
+        for (uint32_t p : acc.leaf_prim) { if (p == LPT_INVALID_INDEX) continue; if (p >= n_baked || seen[p]++) bad_refs++; }   // holes: unused triangle places
     for (size_t i = 0; i < n_baked; ++i) if (!seen[i]) bad_refs++;
 
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
@@ -178,7 +176,7 @@ int main(int argc, char **argv) {
         if (h.prim != 0xFFFFFFFFu) hits++;
         if (brute) {
             Hit b;
-            for (uint32_t ti = 0; ti < (uint32_t)acc.woop.size() && n_baked; ++ti) consider(acc, ti, o, d, b);
+            for (uint32_t ti = 0; ti < (uint32_t)acc.woop.size() && n_baked; ++ti) if (acc.leaf_prim[ti] != LPT_INVALID_INDEX) consider(acc, ti, o, d, b);
             if (b.prim != h.prim || b.t != h.t) mismatches++;
         }
     }
