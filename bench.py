@@ -71,8 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--texture-size", type=int, default=1024, help="experiments only (SURVEY §8d: 1024)")
     ap.add_argument("--emulate-shard", type=int, default=0, help="experiments: render only rank 0's tiles of an N-way shard on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="take the N>1 code path (process group, communicator, exchange) even with one rank")
-    ap.add_argument("--exchange", choices=["gather", "reduce", "host"], default="gather",
-                    help="frame exchange for N>1: owned tiles only (W*H/N*16 B per rank, grouped send/recv), the dense ncclReduce of the accumulation buffer, or "
+    ap.add_argument("--exchange", choices=["auto", "gather", "reduce", "host"], default="auto",
+                    help="frame exchange for N>1.  auto (default): RCCL is brought up under a 60 s watchdog (on a timeout or an error the run continues RCCL-free and says so in "
+                         "`rccl.error`), every form that came up gets 5 calibration frames, the timed region uses the fastest (`config.exchange`, `exchange_auto`) — the "
+                         "headline cannot be lost to RCCL code that has never run with N > 1.  gather: owned tiles only (W*H/N*16 B per rank, grouped send/recv), reduce: the dense ncclReduce of the accumulation buffer, or "
                          "`host`: no exchange on the GPUs — every rank writes its owned pixels straight into ONE shared-memory frame (lpt_renderer_read_radiance_owned; "
                          "each GPU's 1/N over its own PCIe link), completed by a host-side barrier")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N>1: skip the legs that time the two exchange forms the timed region did not use (tests that do not look at them)")
@@ -82,6 +84,10 @@ def parse_args(argv=None):
                     "rank 0 also unpacks, resolves and reads back the frame, so it gets fewer tiles; 0 = calibrate in the warm-up, 8 = equal shares")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="experiments: lpt_renderer_set_option on every renderer (loupiote_amd._abi.OPTIONS: the five lpt_option values and the "
                     "LPT_OPT_EXPERIMENT knobs, by name: path_rays, coop_rays, tail_lanes, packet_primary, wavefront_rays; pipe_rays, refill, trace_waves_per_cu, ...); every value gives the same frame")
+    ap.add_argument("--gltf", action="append", default=[], metavar="PATH", help="render the supplied glTF / GLB asset(s) — repeat the flag to load several into one scene, as the reference's "
+                    "standalone does with DamagedHelmet.glb + sponza3.glb (crates/standalone/src/lib.rs:107-126) — instead of the synthetic stand-in: same span, same line, `data: real`")
+    ap.add_argument("--probe", default=None, metavar="PATH.hdr", help="--gltf: a Radiance .hdr environment (the reference loads uffizi-large.hdr, lib.rs:109); default: constant grey")
+    ap.add_argument("--camera", default=None, metavar="ox,oy,oz,dx,dy,dz", help="--gltf: camera origin and direction (default: the Cornell fixture's, (0,0.6,13.5) looking down -z)")
     ap.add_argument("--sort", type=int, default=0, help="experiments: lpt_renderer_set_sort_queues(flag) on every renderer (1 | 2: outgoing queues by octant)")
     ap.add_argument("--no-shard-emulation", action="store_true", help="skip the shard_emulation leg (rank 0's 1/2, 1/4, 1/8 tile shard of the frame on this GPU)")
     ap.add_argument("--blit-mode", choices=["pathtrace", "temporal", "denoised"], default="pathtrace",
@@ -235,7 +241,15 @@ def cpu_baseline(desc, view, threads, T):
     as many as fit in ~12 s of wall time."""
     from oracle import orc  # checker only: the baseline leg, never the product path
     from oracle import harness
-    s = harness.to_oracle(desc)
+    flags = orc.use_native_build()   # BASELINE.md §3: -O3 -march=native, built here on the host it is timed on (this leg is the last thing the process does with the oracle)
+    if "gltf" in desc:     # --gltf: the oracle's own loader reads the same bytes
+        from oracle import gltf_oracle as G
+        s = G.Scene()
+        for blob in desc["gltf"]:
+            G.load_gltf(blob, s)
+        s.lights[0] = T.cornell_light()[0]
+    else:
+        s = harness.to_oracle(desc)
     sc = orc.OracleScene.from_scene(s, probe=desc["probe"])
     rays, secs, frames = 0, 0.0, 0
     while frames < 64 and secs < 12.0:   # whole 1-spp frames until ~12 s of wall time have been spent
@@ -249,7 +263,7 @@ def cpu_baseline(desc, view, threads, T):
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu": cpu, "cpu_quota": "threads = the cgroup CPU quota (cpu.max) when there is one",
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "threads": threads, "flags": "gcc " + flags, "kind": "port", "nproc": os.cpu_count(), "cpu": cpu, "cpu_quota": "threads = the cgroup CPU quota (cpu.max) when there is one",
             "per_thread": rays / secs / 1e6 / max(threads, 1),
             "sample": "oracle/lpt_oracle.c (scalar C, persistent pthread pool, SAH BVH2, 16x16 tiles): %d whole 1-spp frames of the same 1920x1080 depth-8 "
                       "workload with the seeds of the GPU frame's 1st, 2nd ... sample (%.1f Mrays in %.1f s); a reported baseline, not a target" % (frames, rays / 1e6, secs)}
@@ -373,17 +387,62 @@ def run(args):
     extras = not args.no_extras
     # frames in flight over several communicators has never run on more than one GPU: on N>1 it is opt-in, so that an
     # untested leg cannot take the headline measurement down with it
+    import threading
+    auto = args.exchange == "auto"
+    if auto and not use_dist:
+        args.exchange = "gather"   # one rank: nothing is exchanged
+        auto = False
     tp_leg = extras and (world == 1 or (args.throughput and args.exchange != "host"))
     host_gather = args.exchange == "host" and world > 1
     comms = []
+    rccl_error = None        # auto: why the run continued RCCL-free
+    hard_exit = [False]      # a thread was abandoned inside RCCL: leave through os._exit (its teardown may never return)
+
+    def in_watchdog(fn, seconds, what):
+        """fn() in a thread of its own, joined for `seconds`; the ranks then agree (gloo) on whether EVERY rank finished it.  A thread that did not return is abandoned where
+        it is — never killed, the process never restarted — and the caller goes on without what it was bringing up.  Returns (result, error)."""
+        res = {"value": None, "error": None}
+
+        def work():
+            try:
+                res["value"] = fn()
+            except Exception as e:   # noqa: BLE001 - anything RCCL throws must not cost the line
+                res["error"] = "%s: %s: %s" % (what, type(e).__name__, e)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(seconds)
+        if th.is_alive():
+            res["error"] = "%s did not return within %d s on rank %d (abandoned in its thread)" % (what, int(seconds), rank)
+            hard_exit[0] = True
+        errs = [None] * world
+        dist.all_gather_object(errs, res["error"])
+        err = next((e for e in errs if e), None)
+        return res["value"], err
+
     if use_dist and not host_gather:
         # one communicator for the timed renderer + one per pipelined renderer of the throughput measurement: RCCL serialises
         # the operations of ONE communicator, so frames in flight must not share one
         n_comms = 1 + (P if tp_leg else 0)
-        box = [[lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        for uid in box[0]:
-            comms.append(lp.Comm(dev, uid, rank, world))   # ncclCommInitRank inside the library (RCCL over xGMI)
+        if auto:
+            ids, rccl_error = in_watchdog(lambda: [lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None, 30.0, "ncclGetUniqueId")
+            if rccl_error is None:
+                box = [ids]
+                dist.broadcast_object_list(box, src=0)
+                got, rccl_error = in_watchdog(lambda: [lp.Comm(dev, uid, rank, world) for uid in box[0]], 60.0, "ncclCommInitRank")
+                if rccl_error is None:
+                    comms = got
+            if rccl_error is not None and args.blit_mode != "pathtrace":
+                raise SystemExit("bench.py: RCCL did not come up (%s) and --blit-mode %s needs it (the filter's inputs travel by RCCL)" % (rccl_error, args.blit_mode))
+            if rccl_error is not None:
+                print("bench.py: RCCL did not come up (%s): continuing with the host-side gather" % rccl_error, file=sys.stderr)
+                args.exchange, auto = "host", False
+                host_gather = world > 1
+                tp_leg = False
+        else:
+            box = [[lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            for uid in box[0]:
+                comms.append(lp.Comm(dev, uid, rank, world))   # ncclCommInitRank inside the library (RCCL over xGMI)
     xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
     # host-side gather: ONE frame in POSIX shared memory that every rank maps and page-locks, and its frame barrier — behind the C ABI
     # (lpt_host_frame_*: shm + hipHostRegister + progress words with pause-spinning, then futex).  Every N>1 run gets one: the three exchange
@@ -401,9 +460,27 @@ def run(args):
     def host_frame_barrier():
         """every rank has written its pixels of this frame: lpt_host_frame_barrier (the frame number is the HostFrame's own counter)"""
         shared.barrier(rank)
-    desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"), texture_size=args.texture_size)
-    tex_bytes = int(sum(im.size for im in desc["images"]))
-    scene = scenes.to_product(desc)
+    if args.gltf:
+        # a real asset (VERDICT r05 #6): the reference's loader path — load_gltf per file into ONE scene (lib.rs:117-123), the light of the Cornell fixture, an .hdr
+        # environment if one is given — through the same C ABI the synthetic scene takes
+        scene = lp.Scene()
+        blobs = []
+        for pth in args.gltf:
+            blobs.append(open(pth, "rb").read())
+            lp.loaders.load_gltf(blobs[-1], scene)
+        scene.set_light(0, T.cornell_light())
+        cam = [float(x) for x in args.camera.split(",")] if args.camera else list(T.CORNELL_EYE) + list(T.CORNELL_DIR)
+        if len(cam) != 6:
+            raise SystemExit("bench.py: --camera takes ox,oy,oz,dx,dy,dz")
+        cnt = scene.counts()
+        desc = {"gltf": blobs, "images": [None] * max(int(cnt.images) - 1, 0), "materials": [None] * max(int(cnt.materials) - 1, 0),   # (element 0 of every array is the reference's dummy)
+                "probe": lp.load_env(open(args.probe, "rb").read()) if args.probe else T.CORNELL_PROBE,
+                "camera": {"origin": tuple(cam[:3]), "direction": tuple(cam[3:])}, "name": " + ".join(os.path.basename(pth) for pth in args.gltf)}
+        tex_bytes = 0     # (decoded inside the library; accel.texture_bytes_resident has the resident figure)
+    else:
+        desc = scenes.synthetic_atrium(textures=not os.environ.get("LPT_BENCH_NOTEX"), texture_size=args.texture_size)
+        tex_bytes = int(sum(im.size for im in desc["images"]))
+        scene = scenes.to_product(desc)
     sg = lp.SceneGPU.new_from_scene(scene, dev, gpu_build=bool(os.environ.get("LPT_BENCH_GPU_BUILD")))
     probe = lp.ProbeGPU(dev, desc["probe"], desc["probe"].shape[1], desc["probe"].shape[0])
     view = T.look(desc["camera"]["origin"], desc["camera"]["direction"])
@@ -485,6 +562,50 @@ def run(args):
         else:
             rr.synchronize()
 
+    # --exchange auto: 5 calibration frames of every form that came up (equal tile shares, fresh renderers, each leg under the watchdog), the fastest ends the timed frames
+    exchange_auto = None
+    if auto:
+        exchange_auto = {"what": "ms per frame (max over ranks) of 5 frames after 2 warm-up frames per exchange form, equal tile shares; the fastest is the timed region's",
+                         "calibration_ms_per_frame": {}, "errors": {}}
+        for form in ("host", "gather", "reduce"):
+            if form == "host" and (shared is None or denoising):   # (the denoising modes exchange the filter's inputs: an RCCL form)
+                continue
+
+            def leg(form=form):
+                rr = make_renderer(None if form == "host" else comms[0], lanes=args.lanes or None, host_form=(form == "host"), wts=None)
+                for _ in range(2):
+                    span_frame(rr, form)
+                fence([rr])
+                tc = time.perf_counter()
+                for _ in range(5):
+                    span_frame(rr, form)
+                fence([rr])
+                dt = torch.tensor([time.perf_counter() - tc], dtype=torch.float64)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                rr.close()
+                return float(dt.item()) / 5 * 1e3
+            ms, err = in_watchdog(leg, 90.0, "calibration of the %s form" % form)
+            if err is None:
+                exchange_auto["calibration_ms_per_frame"][form] = ms
+            else:
+                exchange_auto["errors"][form] = err
+                if form != "host":      # an RCCL operation that hangs or fails: no further RCCL in this run
+                    rccl_error = err
+                    break
+        cal = exchange_auto["calibration_ms_per_frame"]
+        box = [min(cal, key=cal.get) if cal else "host"]
+        dist.broadcast_object_list(box, src=0)
+        args.exchange = box[0]
+        exchange_auto["chosen"] = args.exchange
+        auto = False
+        host_gather = args.exchange == "host" and world > 1
+        xmode = lp.EXCHANGE_REDUCE if args.exchange == "reduce" else lp.EXCHANGE_GATHER_TILES
+        if host_gather or rccl_error is not None:
+            tp_leg = False
+        r.close()
+        r = make_renderer(comms[0] if (comms and not host_gather) else None, lanes=args.lanes or None)
+        if args.max_fused:
+            r.set_max_fused(args.max_fused)
     for _ in range(args.warmup):
         for _ in range(FPS):
             span_frame()
@@ -647,8 +768,10 @@ def run(args):
     # really fetched (its own stats variant, above) is `frac_fetched` — a build that fetches more per ray scores higher there, not in `frac`
     fixed = fixed_traversal_counts()
     if fixed and WIDTH == 1920 and HEIGHT == 1080 and SPP == 4:
-        fb_ray = 32.0 + 16.0 + fixed["nodes_per_ray"] * accel.node_bytes + fixed["tris_per_ray"] * accel.tri_bytes
-        fb_sh = 32.0 + 4.0 + fixed["shadow_nodes_per_ray"] * accel.node_bytes + fixed["shadow_tris_per_ray"] * accel.tri_bytes
+        # the committed figure as a whole — SURVEY 8d's S_node = 80 B included: round 6's 64-byte node fetches LESS than the contract's algorithmic bytes, and a
+        # build that moves fewer bytes for the same rays must not score lower for it (what this build's kernel really fetched: frac_fetched, with ITS node size)
+        fb_ray = float(fixed.get("bytes_per_ray", 32.0 + 16.0 + fixed["nodes_per_ray"] * 80.0 + fixed["tris_per_ray"] * 48.0))
+        fb_sh = float(fixed.get("bytes_per_shadow_ray", 32.0 + 4.0 + fixed["shadow_nodes_per_ray"] * 80.0 + fixed["shadow_tris_per_ray"] * 48.0))
         fixed_bytes = ((sc_.closest - sc_.primary) * fb_ray + sc_.shadow * fb_sh) / max(s_launches, 1)
         fixed_achieved = fixed_bytes / (s_avg * 1e-3) / 1e9 if s_avg > 0 else 0.0
     else:   # another workload than config 4 (experiments), or no committed counts: the fetched figure is all there is
@@ -812,7 +935,9 @@ def run(args):
         host_gather_j = {"what": "no exchange on the GPUs: every rank wrote its owned pixels of the mean radiance into ONE shared-memory frame (lpt_renderer_read_radiance_owned), "
                                  "a host-side barrier on shared words completed it", "frame_complete_on_rank0": frame_ok, "per_rank_rays": per_rank, "ranks": world}
     rccl = None
-    if comms:
+    if rccl_error is not None:
+        rccl = {"error": rccl_error, "what": "--exchange auto: RCCL did not come up or an RCCL form failed under the watchdog; the run continued with the forms that work"}
+    elif comms and not host_gather:
         rk, nr = comms[0].info()
         rccl = {"rccl_nranks": nr, "rccl_rank": rk, "communicators_per_rank": len(comms),
                 "exchange_frame_complete_on_rank0": frame_ok,
@@ -840,17 +965,19 @@ def run(args):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "synthetic_atrium(seed=2) [Sponza stand-in: %d triangles, %d textures = %.1f MB of texels, %d materials], %dx%d, %d spp, depth %d, "
-                                   "camera (-10,1,0)->(1,0.35,0); frame = the SURVEY 8d span on one renderer per GPU: reset_accumulation; %d x raytrace(view) "
+            "data": "real" if args.gltf else "synthetic",
+            "config": {"workload": ("--gltf %s" % desc["name"] if args.gltf else "synthetic_atrium(seed=2)") + " [%s%d triangles, %d textures = %.1f MB of texels, %d materials], %dx%d, %d spp, depth %d, "
+                                   "camera %s; frame = the SURVEY 8d span on one renderer per GPU: reset_accumulation; %d x raytrace(view) "
                                    "(recorded; submitted by the read as 4-sample wavefronts over runs of tile rows)%s; read_radiance() into %s host memory on rank 0; step = %d frames"
-                                   % (accel.triangles, len(desc["images"]), tex_bytes / 1e6, len(desc["materials"]), WIDTH, HEIGHT, SPP, DEPTH, SPP,
+                                   % ("" if args.gltf else "Sponza stand-in: ", accel.triangles, len(desc["images"]), (accel.texture_bytes_resident if args.gltf else tex_bytes) / 1e6, len(desc["materials"]),
+                                      WIDTH, HEIGHT, SPP, DEPTH, "%r->%r" % (tuple(desc["camera"]["origin"]), tuple(desc["camera"]["direction"])) if args.gltf else "(-10,1,0)->(1,0.35,0)", SPP,
                                       "; lpt_renderer_exchange(%s)" % args.exchange if use_dist else "", "pageable" if args.pageable else "page-locked", FPS),
                        "texture_bytes": tex_bytes, "textures": len(desc["images"]), "materials": len(desc["materials"]),
                        "texture_bytes_resident": int(accel.texture_bytes_resident), "texture_pairs": int(accel.texture_pairs),
                        "frames_per_step": FPS, "frames_timed": n_frames, "timed_region_s": elapsed, "submission": "eager" if args.eager else "record-then-submit",
                        "raytrace_calls_per_frame": (sub1[0] - sub0[0]) / max(args.steps * FPS, 1), "wavefronts_per_frame": (sub1[1] - sub0[1]) / max(args.steps * FPS, 1),
-                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": (args.exchange + " (native RCCL, lpt_renderer_exchange)") if use_dist else "none",
+                       "tiles": "32x8 interleaved, tile_id mod N", "exchange": ((args.exchange + (" (host-side gather: lpt_host_frame_*, no collective)" if args.exchange == "host" else " (native RCCL, lpt_renderer_exchange)")
+                                     + (" — picked by --exchange auto" if exchange_auto or rccl_error else "")) if use_dist else "none"),
                        "rays_per_frame": (closest + shadow) / n_frames, "rays_per_step": (closest + shadow) / args.steps,
                        "closest_rays": closest, "shadow_rays": shadow, "shaded_hits": shaded, "frame_complete": frame_ok, "frame_checksum": checksum,
                        "library_options": lib_options},
@@ -865,6 +992,7 @@ def run(args):
             "rccl": rccl,
             "host_gather": host_gather_j,
             "exchange_forms": None,      # filled in below: the legs run after the line is assembled (a watchdog prints it if they hang)
+            "exchange_auto": exchange_auto,
             "stage_ms_per_rank": stage_ms_ranks,
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": fixed_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": rf_frac,
@@ -910,7 +1038,6 @@ def run(args):
     # The legs below run RCCL calls that have never executed with more than one rank anywhere (ncclReduce; ncclSend / ncclRecv when the main form was `host`): a hang
     # there must not cost the line.  A watchdog on every rank: after 180 s rank 0 prints the line it has (exchange_forms = the legs finished so far + the
     # timeout) and every rank leaves at once.
-    import threading
     wd_state = {"done": False}
 
     def wd_bail():
@@ -925,7 +1052,7 @@ def run(args):
                 pass
             sys.stdout.flush()
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)      # the line is out, but a leg hung: launchers and CI must see that
     watchdog = threading.Timer(180.0, wd_bail)
     watchdog.daemon = True
     if use_dist and (world > 1 or args.force_dist):
@@ -950,6 +1077,8 @@ def run(args):
                         raise RuntimeError("no shared host frame (one rank)")
                     rr = make_renderer(None, lanes=args.lanes or None, host_form=True, wts=None)
                 else:
+                    if rccl_error is not None:         # --exchange auto found RCCL unusable: not tried again
+                        raise RuntimeError(rccl_error)
                     if not comms and not lazy_comms:   # the main form was `host`: RCCL comes up only now (and a failure here cannot take the headline down)
                         box = [lp.Comm.unique_id() if rank == 0 else None]
                         dist.broadcast_object_list(box, src=0)
@@ -996,6 +1125,12 @@ def run(args):
     if shared is not None:
         last.pop("img", None)
         shared.close()       # unregister + unmap; the creator (rank 0) unlinks
+    if hard_exit[0]:
+        # a thread sits in an RCCL call that never returned: a communicator's teardown may not return either.  The line is complete: print it and leave
+        if out is not None:
+            sys.stdout.flush()
+            print(json.dumps(out), flush=True)
+        os._exit(0)
     for c in comms + lazy_comms:
         c.close()
     if use_dist:

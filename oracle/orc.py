@@ -47,10 +47,29 @@ def build(force=False):
     return so
 
 
-def lib():
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off"   # oracle/Makefile NATIVE_CFLAGS
+CHECKER_FLAGS = "-O2 -march=x86-64-v3 -ffp-contract=off"
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg only: from here on this process runs the oracle built with -O3 -march=native ON THIS HOST, made now.
+    Returns the flags that are in effect (the checker's if the native build fails: no compiler, an unknown CPU).  Same source, same arithmetic
+    (-ffp-contract=off either way)."""
+    global _LIB
+    so = os.path.join(_HERE, "liblpt_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liblpt_oracle_native.so"])
+    except Exception:
+        return CHECKER_FLAGS
+    _LIB = None
+    lib(so)
+    return NATIVE_FLAGS
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(path or build())
         vp, u32, f32p = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
         L.orc_scene_create.restype = vp
         L.orc_scene_create.argtypes = [u32, vp, vp, u32, vp, u32, vp, u32, vp, u32, u32, vp]

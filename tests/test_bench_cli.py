@@ -13,8 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_help_and_contract_flags():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
-    for flag in ("--gpus", "--steps", "--warmup", "--exchange", "--pipeline", "--emulate-shard", "--spawn-dry-run"):
+    for flag in ("--gpus", "--steps", "--warmup", "--exchange", "--pipeline", "--emulate-shard", "--spawn-dry-run", "--gltf", "--probe", "--camera"):
         assert flag in p.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--gltf", "a.glb", "--gltf", "b.glb", "--probe", "e.hdr", "--camera", "0,1,2,0,0,-1"])
+    assert a.gltf == ["a.glb", "b.glb"] and a.probe == "e.hdr" and a.exchange == "auto"     # real assets, when they appear, take the same span; N>1 defaults to auto
 
 
 def test_bench_starts_its_own_ranks_and_they_rendezvous():

@@ -73,7 +73,7 @@ def test_the_drivers_launcher_command_line(fake_rccl):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--root-weight", "8", "--no-extras"] + SMALL
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--root-weight", "8", "--exchange", "gather", "--no-extras"] + SMALL
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -90,10 +90,10 @@ def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processe
     processes (BASELINE config 5's form): the filter inputs travel after every call, rank 0 filters, its tile weight is calibrated with
     the filter in the frame (VERDICT r03 #4 iv) — the presented frame equals the one-process frame bit for bit."""
     one = _bench(["--no-extras"])
-    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--group-bracket", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
+    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--exchange", "gather", "--group-bracket", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     assert j["rccl"]["exchange_frame_complete_on_rank0"] is True and j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
     t1 = _bench(["--blit-mode", "temporal", "--no-extras", "--no-shard-emulation"])
-    for extra in (["--root-weight", "8"], ["--group-bracket"], ["--exchange", "reduce"]):
+    for extra in (["--root-weight", "8", "--exchange", "gather"], ["--group-bracket", "--exchange", "gather"], ["--exchange", "reduce"]):
         t2 = _bench(["--gpus", "2", "--oversubscribe", "--blit-mode", "temporal", "--no-extras"] + extra, {"LPT_RCCL_LIBRARY": fake_rccl})
         assert t2["rccl"]["exchange_frame_complete_on_rank0"] is True, extra
         assert t2["config"]["frame_checksum"] == t1["config"]["frame_checksum"], extra
@@ -132,14 +132,14 @@ def test_one_run_times_all_three_exchange_forms(fake_rccl):
 
 
 def test_calibrated_tile_weight_latency_and_frames_in_flight_over_several_communicators(fake_rccl):
-    j = _bench(["--gpus", "2", "--oversubscribe", "--throughput", "--pipeline", "2"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
+    j = _bench(["--gpus", "2", "--oversubscribe", "--exchange", "gather", "--throughput", "--pipeline", "2"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     r = j["rccl"]
     assert r["rccl_nranks"] == 2 and r["communicators_per_rank"] == 3 and r["exchange_frame_complete_on_rank0"] is True
     assert len(r["tile_weights"]) == 2 and 1 <= r["tile_weights"][0] <= 8 and r["tile_weights"][1] in (1, 8)
     assert r["tile_weight_calibration"]["rank0_extra_ms"] >= 0.0
     assert j["throughput"]["communicators"] == 2 and j["throughput"]["value"] > 0 and j["latency_ms"]["median"] > 0
     # a forced weight: rank 0 traces 3/11 of the tiles
-    k = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "3", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
+    k = _bench(["--gpus", "2", "--oversubscribe", "--exchange", "gather", "--root-weight", "3", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     assert k["rccl"]["tile_weights"] == [3, 8] and k["rccl"]["exchange_frame_complete_on_rank0"] is True
     a, b = k["rccl"]["per_rank_rays"]
     assert 0.2 < a / (a + b) < 0.35
@@ -150,3 +150,47 @@ def test_a_missing_rccl_library_is_a_loud_error():
     env["LPT_RCCL_LIBRARY"] = "/nonexistent/librccl.so"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--force-dist", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0 and "librccl could not be loaded" in (p.stderr + p.stdout)
+
+
+def test_exchange_auto_picks_the_fastest_form_that_came_up(fake_rccl):
+    """`--exchange auto` (the default for N > 1): RCCL comes up under a watchdog, every form gets calibration frames, the timed region uses the
+    fastest — and the line says which, with all three forms still reported and their checksums equal"""
+    one = _bench(["--no-extras"])
+    j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})     # no --exchange: auto
+    ea = j["exchange_auto"]
+    assert set(ea["calibration_ms_per_frame"]) == {"host", "gather", "reduce"} and not ea["errors"], ea
+    assert ea["chosen"] == min(ea["calibration_ms_per_frame"], key=ea["calibration_ms_per_frame"].get)
+    assert j["config"]["exchange"].startswith(ea["chosen"]) and "auto" in j["config"]["exchange"]
+    assert j["config"]["frame_complete"] is True and j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    ef = j["exchange_forms"]
+    assert ef["checksums_equal"] is True and all("error" not in ef[f] for f in ("gather", "reduce", "host")), ef
+    assert ef[ea["chosen"]]["timed_region"] is True
+    assert (j["rccl"] is None) == (ea["chosen"] == "host") or "error" not in (j["rccl"] or {})
+
+
+def test_exchange_auto_survives_an_rccl_bring_up_that_never_returns(fake_rccl):
+    """the stand-in's ncclCommInitRank blocks forever (FAKE_RCCL_HANG_INIT): after the watchdog's 60 s the run continues RCCL-free — the line appears, its frame is
+    the one-process frame, `config.exchange` says host, `rccl.error` says why, the RCCL forms are reported as errors; the stuck thread is abandoned, nothing is
+    restarted and the process leaves with status 0"""
+    one = _bench(["--no-extras"])
+    j = _bench(["--gpus", "2", "--oversubscribe", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl, "FAKE_RCCL_HANG_INIT": "1"})
+    assert j["n_gpus"] == 2 and j["config"]["exchange"].startswith("host")
+    assert "ncclCommInitRank did not return" in j["rccl"]["error"]
+    assert j["host_gather"]["frame_complete_on_rank0"] is True
+    assert j["config"]["frame_checksum"] == one["config"]["frame_checksum"] and j["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    ef = j["exchange_forms"]
+    assert ef["host"]["timed_region"] is True and "error" in ef["gather"] and "error" in ef["reduce"]
+
+
+def test_bench_renders_a_supplied_gltf_with_the_same_span():
+    """`bench.py --gltf PATH` (the reference's own assets — DamagedHelmet.glb, sponza3.glb, uffizi-large.hdr — are not in its tree; the Cornell box is):
+    the loader's scene instead of the stand-in, the same timed span and line, `data: real`, and the CPU baseline leg reads the same bytes through the oracle's loader"""
+    glb = os.path.join(ROOT, "tests", "golden", "cornell-box.glb")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--frames-per-step", "2", "--width", "256", "--height", "256", "--no-extras",
+                        "--gltf", glb], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["data"] == "real" and "cornell-box.glb" in j["config"]["workload"] and j["config"]["frame_complete"] is True
+    assert 0 < j["accel"]["triangles"] < 100 and j["value"] > 0 and j["config"]["frame_checksum"] > 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and "-march=native" in j["cpu_baseline"]["flags"] and j["cpu_baseline"]["threads"] >= 1

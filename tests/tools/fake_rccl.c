@@ -65,6 +65,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
 }
 
 ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int rank) {
+    if (getenv("FAKE_RCCL_HANG_INIT")) for (;;) nap();   /* tests: an RCCL bring-up that never returns (bench.py --exchange auto must go on without it) */
     if (world < 1 || world > MAX_RANKS || rank < 0 || rank >= world) return ncclInvalidArgument;
     struct fake_comm *c = (struct fake_comm *)calloc(1, sizeof *c);
     snprintf(c->name, sizeof c->name, "/%.*s", 70, id.internal);
