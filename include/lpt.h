@@ -433,7 +433,10 @@ int lpt_host_frame_attach(const char *name, uint32_t width, uint32_t height, uin
 /* the frame: width * height * 4 floats, row-major, in page-locked shared memory (valid until lpt_host_frame_destroy) */
 int lpt_host_frame_ptr(lpt_host_frame *f, float **frame);
 /* returns when every one of the `world` participants has called it with this frame number (1, 2, 3, ...: the caller's frame counter, the same
- * on every rank; a rank calls it after its lpt_renderer_read_radiance_owned of that frame has returned).  LPT_ERR_READBACK after timeout_ms. */
+ * on every rank; a rank calls it after its lpt_renderer_read_radiance_owned of that frame has returned).  LPT_ERR_READBACK after timeout_ms.
+ * ARRIVE-ONLY over ONE frame: once it returns, frame `frame_no` is complete — and any rank may start writing frame_no + 1 into the same segment.  A consumer that
+ * still reads frame_no (rank 0 encoding it, a LPT_HOST_FRAME_HOST_ONLY participant) must hold the writers back itself: a SECOND barrier call (another frame number,
+ * e.g. 2 k for "written" and 2 k + 1 for "consumed": bench.py and examples/multi_gpu.c do this) before anybody's next lpt_renderer_read_radiance_owned, or a copy. */
 int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, uint32_t timeout_ms);
 int lpt_host_frame_destroy(lpt_host_frame *f);
 /* replaces: renderer.queries.values()/labels()

@@ -10,7 +10,7 @@
 //   k_lbvh_collapse one launch per LEVEL of the wide tree: every 8-wide node opens its binary subtree greedily
 //                   (largest box first) into <= 8 children, subtrees of <= 2 triangles become leaf children;
 //                   children get octant-ordered slots; an exclusive scan over the level gives child / triangle bases
-//   k_lbvh_emit     node topology (imask, leaf masks, bases), leaf order (leaf_prim, tri_slot), the next level's work list
+//   k_lbvh_emit     node topology (imask, leaf masks, bases), the triangles' places (leaf_prim), the next level's work list
 //   k_refit_level   (kernels.h) then fills every node's grid origin / exponents / quantised planes bottom-up.
 // The tree only decides WHICH boxes are visited; hits are decided by the Woop test and the (t, prim id) tie rule,
 // so a scene built here renders bit-identically to one built by the host SAH builder (tests/test_gpu_lbvh.py).
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_lbvh_collapse(LbvhTree T, LbvhLevel L) {
 }
 
 __global__ __launch_bounds__(64) void k_lbvh_emit(LbvhTree T, LbvhLevel L, const uint32_t *inner_off, const uint32_t *tri_off, uint32_t level_first,
-                                                   uint32_t next_first, uint32_t tri_first, uint4 *nodes, uint32_t *leaf_prim, uint32_t *tri_slot, int *next_items) {
+                                                   uint32_t next_first, uint32_t tri_first, uint4 *nodes, uint32_t *leaf_prim, int *next_items) {
     const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= L.n_items) return;
     const uint32_t child_base = next_first + inner_off[it], tri_base = (level_first + it) * kNodeTris;   // fixed triangle places: 16 * node + 2 * slot + k (common.h Node8)
@@ -218,7 +218,6 @@ __global__ __launch_bounds__(64) void k_lbvh_emit(LbvhTree T, LbvhLevel L, const
             for (uint32_t k = 0; k < cnt; ++k) {
                 const uint32_t prim = T.sorted_tri[first + k];
                 leaf_prim[tri_base + 2u * (uint32_t)s + k] = prim;
-                tri_slot[prim] = tri_base + 2u * (uint32_t)s + k;
             }
         }
     }
@@ -244,14 +243,16 @@ __global__ __launch_bounds__(256) void k_lbvh_bounds(DScene sc, uint32_t n, int 
         for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], lbvh_f2o(lo[a])); atomicMax(&bounds[3 + a], lbvh_f2o(hi[a])); }
 }
 
-// prim-ordered Woop maps -> leaf order
-__global__ __launch_bounds__(256) void k_lbvh_scatter_woop(const float4 *src, float4 *woop, const uint32_t *tri_slot, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = tri_slot[i];
-    woop[3u * (size_t)slot] = src[3u * (size_t)i];
-    woop[3u * (size_t)slot + 1] = src[3u * (size_t)i + 1];
-    woop[3u * (size_t)slot + 2] = src[3u * (size_t)i + 2];
+// prim-ordered Woop maps -> the triangles' places in the tree.  PLACE-driven (every place looks up its triangle): a triangle the host builder split
+// (bvh.cpp presplit) has several places, a hole has none.  Only the places of triangles [first, first + count) are written.
+__global__ __launch_bounds__(256) void k_lbvh_scatter_woop(const float4 *src, float4 *woop, const uint32_t *leaf_prim, uint32_t n_places, uint32_t first, uint32_t count) {
+    const uint32_t place = blockIdx.x * blockDim.x + threadIdx.x;
+    if (place >= n_places) return;
+    const uint32_t prim = leaf_prim[place];
+    if (prim - first >= count) return;     // (holes are 0xFFFFFFFF)
+    woop[3u * (size_t)place] = src[3u * (size_t)prim];
+    woop[3u * (size_t)place + 1] = src[3u * (size_t)prim + 1];
+    woop[3u * (size_t)place + 2] = src[3u * (size_t)prim + 2];
 }
 
 }  // namespace lptd

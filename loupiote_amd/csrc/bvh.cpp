@@ -413,6 +413,145 @@ Box padded_box(const lpt_vertex *v, float pad_abs) {
     return b;
 }
 
+// ---- TRIANGLE PRE-SPLITTING (round 6).  A triangle much larger than its neighbours — a wall of two triangles around finely tessellated
+// ornaments, a long sliver across the hall — drags its whole bounding box through the tree: on the bench scene with its shell as two-triangle quads a ray tested 22.4
+// triangles instead of 4.3 and the frame took 32.8 ms instead of 10.4 (profiles/r06_configs_timing.jsonl).  Before the build, the LARGEST references are split at the
+// middle of their box's longest axis — the triangle clipped against both halves (Sutherland-Hodgman, binary64), each half's box = the clipped polygon's, padded like a
+// triangle's — until no reference's EMPTY box area (below) exceeds kSplitRatio times the mean box area, or the budget of kSplitBudget extra references per triangle is
+// spent.  What is split is decided by emptiness, not size: a ray enters a box in proportion to its surface and hits the triangle in proportion to its area, so
+// half_area(box) - 2 * area(triangle part) is the share of entries that cannot end in a hit.  A wall of two axis-aligned triangles fills its (flat) box: nothing to gain,
+// and splitting it by size alone cost 9 % on the quad-shelled atrium (more references along every wall); a sliver across the hall leaves its box empty: splitting it
+// took the mixed-scale hall from 21.1 to 16.2 ms per frame (profiles/r06_experiments_ab.txt E).  The tree then holds a
+// split triangle in several leaves: a ray may test it more than once (the closest-hit rule does not care), every point of it lies in at least one reference's box (the
+// halves share their cut, the padding covers the clipping's rounding), so the boxes stay conservative and only the Woop test decides (SPEC §7): frames are unchanged.
+// A scene of evenly sized triangles (the bench stand-in: largest box 10 x the mean) is not touched.  A refit (lpt_scene_gpu_update_instances) recomputes leaf boxes
+// from whole triangles: correct, and as loose as before the split, until the next upload.
+constexpr float kSplitRatio = 4.0f;     // a reference is split while the EMPTY part of its box's half area exceeds this many times the mean box half area
+constexpr float kSplitBudget = 0.3f;    // at most this many extra references per triangle
+
+// the triangle's part inside the box [lo, hi]: its bounds (false: nothing of it is inside)
+static bool clipped_bounds(const lpt_vertex *v, const double lo[3], const double hi[3], double blo[3], double bhi[3], double &area) {
+    double poly[16][3], tmp[16][3];
+    int np = 3;
+    for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) poly[k][a] = (double)v[k].position[a];
+    for (int a = 0; a < 3 && np; ++a)
+        for (int side = 0; side < 2 && np; ++side) {
+            const double plane = side ? hi[a] : lo[a], sgn = side ? -1.0 : 1.0;     // inside: sgn * (x - plane) >= 0
+            int nt = 0;
+            for (int i = 0; i < np; ++i) {
+                const double *p = poly[i], *q = poly[(i + 1) % np];
+                const double dp = sgn * (p[a] - plane), dq = sgn * (q[a] - plane);
+                if (dp >= 0.0) { for (int c = 0; c < 3; ++c) tmp[nt][c] = p[c]; nt++; }
+                if ((dp >= 0.0) != (dq >= 0.0)) {
+                    const double t = dp / (dp - dq);
+                    for (int c = 0; c < 3; ++c) tmp[nt][c] = p[c] + t * (q[c] - p[c]);
+                    tmp[nt][a] = plane;
+                    nt++;
+                }
+            }
+            np = std::min(nt, 15);
+            memcpy(poly, tmp, sizeof(double) * 3 * (size_t)np);
+        }
+    if (np < 1) return false;
+    for (int a = 0; a < 3; ++a) { blo[a] = 1e300; bhi[a] = -1e300; }
+    for (int i = 0; i < np; ++i) for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], poly[i][a]); bhi[a] = std::max(bhi[a], poly[i][a]); }
+    double nx = 0.0, ny = 0.0, nz = 0.0;     // the (planar, convex) polygon's area: half the norm of the summed fan cross products
+    for (int i = 1; i + 1 < np; ++i) {
+        const double ux = poly[i][0] - poly[0][0], uy = poly[i][1] - poly[0][1], uz = poly[i][2] - poly[0][2];
+        const double wx = poly[i + 1][0] - poly[0][0], wy = poly[i + 1][1] - poly[0][1], wz = poly[i + 1][2] - poly[0][2];
+        nx += uy * wz - uz * wy; ny += uz * wx - ux * wz; nz += ux * wy - uy * wx;
+    }
+    area = 0.5 * std::sqrt(nx * nx + ny * ny + nz * nz);
+    return true;
+}
+
+static Box padded_from(const double blo[3], const double bhi[3], float pad_abs) {
+    Box b;
+    for (int a = 0; a < 3; ++a) {
+        // outward to fp32, then the triangle padding (padded_box): the clipping's own rounding is far inside it
+        float l = (float)blo[a], h = (float)bhi[a];
+        if ((double)l > blo[a]) l = std::nextafter(l, -3.0e38f);
+        if ((double)h < bhi[a]) h = std::nextafter(h, 3.0e38f);
+        const float m = std::max(fabsf(l), fabsf(h));
+        const float e = 4e-6f * m + pad_abs + 1e-6f * (h - l) + 1e-30f;
+        b.lo[a] = l - e;
+        b.hi[a] = h + e;
+    }
+    return b;
+}
+
+static void presplit(const std::vector<lpt_vertex> &tri_verts, float pad_abs, std::vector<Ref> &refs) {
+    const size_t n = refs.size();
+    if (n < 2) return;
+    double sum = 0.0;
+    for (const Ref &r : refs) sum += (double)r.box.half_area();
+    if (!(sum > 0.0)) return;
+    auto tri_area = [&](uint32_t prim) {
+        const lpt_vertex *v = &tri_verts[3 * (size_t)prim];
+        const double ux = (double)v[1].position[0] - v[0].position[0], uy = (double)v[1].position[1] - v[0].position[1], uz = (double)v[1].position[2] - v[0].position[2];
+        const double wx = (double)v[2].position[0] - v[0].position[0], wy = (double)v[2].position[1] - v[0].position[1], wz = (double)v[2].position[2] - v[0].position[2];
+        const double cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+        return 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+    };
+    // a max-heap of (empty half area of the box, ref index); a reference whose split makes no progress leaves it
+    std::vector<std::pair<float, uint32_t>> heap;
+    heap.reserve(n);
+    for (uint32_t i = 0; i < (uint32_t)n; ++i) heap.push_back({(float)std::max(0.0, (double)refs[i].box.half_area() - 2.0 * tri_area(refs[i].prim)), i});
+    std::make_heap(heap.begin(), heap.end());
+    float ratio = kSplitRatio, budget_f = kSplitBudget;
+    if (const char *ev = lpt_experiment_env("LPT_BVH_SPLIT")) sscanf(ev, "%f,%f", &ratio, &budget_f);   // A/B builds only: "ratio,budget"; "1e30,0" = no splitting
+    const size_t budget = (size_t)((double)n * budget_f);
+    size_t extra = 0;
+    while (!heap.empty() && extra < budget) {
+        const float empty = heap.front().first;
+        const uint32_t idx = heap.front().second;
+        if (!((double)empty > (double)ratio * sum / (double)refs.size())) break;
+        std::pop_heap(heap.begin(), heap.end());
+        heap.pop_back();
+        const Ref r = refs[idx];
+        const float area = r.box.half_area();
+        int ax = 0;
+        for (int a = 1; a < 3; ++a) if (r.box.hi[a] - r.box.lo[a] > r.box.hi[ax] - r.box.lo[ax]) ax = a;
+        const double mid = 0.5 * ((double)r.box.lo[ax] + (double)r.box.hi[ax]);
+        const lpt_vertex *v = &tri_verts[3 * (size_t)r.prim];
+        Box half[2];
+        bool have[2];
+        double part[2] = {0.0, 0.0};
+        for (int side = 0; side < 2; ++side) {
+            double lo[3], hi[3], blo[3], bhi[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = r.box.lo[a]; hi[a] = r.box.hi[a]; }
+            (side ? lo : hi)[ax] = mid;
+            have[side] = clipped_bounds(v, lo, hi, blo, bhi, part[side]);
+            if (have[side]) {
+                half[side] = padded_from(blo, bhi, pad_abs);
+                for (int a = 0; a < 3; ++a) { half[side].lo[a] = std::max(half[side].lo[a], r.box.lo[a]); half[side].hi[a] = std::min(half[side].hi[a], r.box.hi[a]); }   // never beyond the parent's
+            }
+        }
+        if (!have[0] && !have[1]) continue;   // (cannot happen: the triangle is inside its own box)
+        auto put = [&](uint32_t at, const Box &bx, double tri_part) {
+            refs[at].box = bx;
+            for (int a = 0; a < 3; ++a) refs[at].c[a] = 0.5f * (bx.lo[a] + bx.hi[a]);
+            refs[at].prim = r.prim;
+            const float ha = bx.half_area();
+            if (ha < 0.9f * area) { heap.push_back({(float)std::max(0.0, (double)ha - 2.0 * tri_part), at}); std::push_heap(heap.begin(), heap.end()); }   // no progress: leave it be
+            return ha;
+        };
+        sum -= (double)area;
+        if (have[0] && have[1]) {
+            refs.push_back(r);
+            sum += (double)put(idx, half[0], part[0]);
+            sum += (double)put((uint32_t)refs.size() - 1u, half[1], part[1]);
+            extra++;
+        } else {
+            const int sd = have[0] ? 0 : 1;
+            sum += (double)put(idx, half[sd], part[sd]);   // the triangle only reaches into one half: a tighter box, no new reference
+        }
+    }
+    if (lpt_experiment_env("LPT_BVH_STATS"))
+        fprintf(stderr, "[lpt bvh] presplit: %zu triangles -> %zu references (budget %zu); emptiest box now %.4g, mean box %.4g\n", n, refs.size(), budget,
+                heap.empty() ? 0.0 : (double)heap.front().first, sum / (double)refs.size());
+}
+
 }  // namespace
 
 int bake_and_build(const lpt_scene &scene, Accel &out) {
@@ -456,12 +595,14 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
         for (int a = 0; a < 3; ++a) r.c[a] = 0.5f * (r.box.lo[a] + r.box.hi[a]);
         r.prim = t;
     }
-    b.nodes.reserve(2 * (size_t)n);
+    presplit(out.tri_verts, pad_abs, b.refs);
+    const uint32_t n_refs = (uint32_t)b.refs.size();   // >= n: a split triangle has several references
+    b.nodes.reserve(2 * (size_t)n_refs);
     const char *mode = lpt_experiment_env("LPT_BVH_COLLAPSE");  // "greedy" keeps the round-1 builder for A/B runs
     const bool use_dp = !(mode && strcmp(mode, "greedy") == 0);
     b.leaf_max = use_dp ? 1u : kLeafMax;
-    b.build(0, n, 0);
-    if (use_dp && n >= 64u) {
+    b.build(0, n_refs, 0);
+    if (use_dp && n_refs >= 64u) {
         // LPT_BVH_REINSERT="passes,fraction" (experiments); "0" keeps the tree as the top-down build left it
         // defaults: 4 passes over the 30 % largest boxes — on the 262 k-triangle atrium 2.6 % fewer nodes per ray and 1.7 % less
         // traversal time for 3x the (host) build time; more passes add little (profiles/r03_experiments_ab.txt)
@@ -475,7 +616,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
             if (b.max_depth > 2u * kMaxDepth) {   // moves may deepen a chain without bound on adversarial input: fall back to the depth-capped tree
                 b.nodes.clear();
                 b.max_depth = 0;
-                b.build(0, n, 0);
+                b.build(0, n_refs, 0);
             }
         }
     }
@@ -634,7 +775,7 @@ int bake_and_build(const lpt_scene &scene, Accel &out) {
     }
     out.max_depth = max_depth;
     out.level_start.push_back((uint32_t)out.nodes.size());
-    if (tris_placed != n) return fail(LPT_ERR_ACCEL_BUILD, "internal: %u of %u triangles referenced", tris_placed, n);
+    if (tris_placed != n_refs) return fail(LPT_ERR_ACCEL_BUILD, "internal: %u of %u triangle references placed", tris_placed, n_refs);
     {   // whole nodes' worth of places for every node (the last levels' nodes have no children of their own to make the arrays grow)
         WoopTri hole;
         memset(&hole, 0, sizeof hole);

@@ -127,7 +127,7 @@ struct lpt_scene_gpu {
     std::vector<uint8_t> image_resident;
     lpt_accel_stats stats{};
     // refit bookkeeping (lpt_scene_gpu_update_instances)
-    void *tri_slot = nullptr, *node_lo = nullptr, *node_hi = nullptr;  // prim -> leaf slot; per-node world box
+    void *node_lo = nullptr, *node_hi = nullptr;  // per-node world box
     void *obj_verts = nullptr, *obj_indices = nullptr, *bad_flag = nullptr;  // object-space meshes for device-side re-baking
     void *arena = nullptr;                                                    // scratch of the GPU builder, kept for rebuilds
     size_t arena_bytes = 0;
@@ -325,7 +325,7 @@ static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------- GPU builder (build_kernels.h)
-// Fills sg->nodes / woop / leaf_prim / tri_slot / node_lo / node_hi / level_start from the baked triangles that are
+// Fills sg->nodes / woop / leaf_prim / node_lo / node_hi / level_start from the baked triangles that are
 // already on the device (sg->d.tri_verts).  `woop_prim` = the Woop maps in prim order (host, SPEC §6).
 // `host_woop`: the Woop maps in prim order on the host (upload path) or nullptr when `dev_woop` (device, prim order) is given.
 // Scene bounds from the baked triangles on the device (blocking), and what follows from them for every kernel that pads a triangle or writes a node: the scene-wide part
@@ -399,10 +399,7 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
     SCR(uint32_t, leaf_big, (size_t)kNodeTris * n)  // their triangle places (16 per node; the final array is cut to the nodes there are)
     SCR(int, items_a, n) SCR(int, items_b, n) SCR(int, kid_ref, 8u * (size_t)n)
     SCR(uint32_t, inner_count, n) SCR(uint32_t, tri_count, n) SCR(uint32_t, inner_off, n) SCR(uint32_t, tri_off, n)
-    void *tri_slot = nullptr;
     LB_TRY(hipMemsetAsync(leaf_big, 0xFF, sizeof(uint32_t) * (size_t)kNodeTris * n, s));   // holes: LPT_INVALID_INDEX
-    LB_TRY(hipMalloc(&tri_slot, sizeof(uint32_t) * n));
-    sg->tri_slot = tri_slot;
     LB_TRY(hipMemsetAsync(items_a, 0, sizeof(int), s));  // level 0 = the binary root
     int *items_cur = items_a, *items_next = items_b;
     uint32_t n_items = 1, level_first = 0, tri_running = 0;
@@ -424,7 +421,7 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
         const uint32_t inner_total = tail[0] + tail[1], tri_total = tail[2] + tail[3];
         if ((size_t)level_first + n_items + inner_total > n) return done(fail(LPT_ERR_ACCEL_BUILD, "GPU BVH build: node budget exceeded"));
         hipLaunchKernelGGL(k_lbvh_emit, dim3(div_up(n_items, 64u)), dim3(64), 0, s, T, L, inner_off, tri_off, level_first, level_first + n_items, tri_running,
-                           nodes_big, leaf_big, (uint32_t *)tri_slot, items_next);
+                           nodes_big, leaf_big, items_next);
         sg->level_start.push_back(level_first);
         level_first += n_items;
         tri_running += tri_total;
@@ -449,7 +446,7 @@ static int build_lbvh(lpt_scene_gpu *sg, uint32_t n, const WoopTri *host_woop, c
         LB_TRY(hipMemcpyAsync(woop_prim, host_woop, sizeof(WoopTri) * (size_t)n, hipMemcpyHostToDevice, s));
         woop_src = woop_prim;
     }
-    hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(b256), dim3(256), 0, s, woop_src, (float4 *)sg->woop, (const uint32_t *)tri_slot, n);
+    hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(kNodeTris * n_nodes, 256u)), dim3(256), 0, s, woop_src, (float4 *)sg->woop, (const uint32_t *)sg->leaf_prim, kNodeTris * n_nodes, 0u, n);
     sg->d.nodes = (const DNode8 *)sg->nodes;
     sg->d.leaf_prim = (const uint32_t *)sg->leaf_prim;
     sg->d.woop = (const float4 *)sg->woop;
@@ -575,7 +572,7 @@ int lpt_scene_gpu_destroy(lpt_scene_gpu *sg) {
     for (lpt_renderer *r : sg->dev->renderers)
         if (r->sg == sg) { r->sg = nullptr; r->resources_set = false; }
     void *ptrs[] = {sg->nodes, sg->woop, sg->leaf_prim, sg->tri_verts, sg->materials, sg->lights, sg->texels, sg->images, sg->srgb_lut,
-                    sg->tri_slot, sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena, sg->pair_texels, sg->pair_images};
+                    sg->node_lo, sg->node_hi, sg->obj_verts, sg->obj_indices, sg->bad_flag, sg->arena, sg->pair_texels, sg->pair_images};
     for (void *p : ptrs) if (p) hipFree(p);
     delete sg;
     return LPT_OK;
@@ -728,10 +725,6 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
     }
     UP(srgb_lut, lut)
     if (!gpu_build) {
-        std::vector<uint32_t> tri_slot(std::max<size_t>(acc.tri_material.size(), 1u), 0u);
-        for (size_t slot = 0; slot < acc.leaf_prim.size(); ++slot)
-            if (acc.leaf_prim[slot] != LPT_INVALID_INDEX) tri_slot[acc.leaf_prim[slot]] = (uint32_t)slot;
-        UP(tri_slot, tri_slot)
         std::vector<float4> boxes(acc.nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));  // filled by the first refit
         UP(node_lo, boxes)
         UP(node_hi, boxes)
@@ -790,7 +783,7 @@ int lpt_scene_upload_ex(lpt_device *dev, const lpt_scene *scene, uint32_t flags,
             st = make_bake_args(sg, *scene, i, first, cnt, a);
             if (st == LPT_OK)
                 hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
-                                   (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
+                                   (float4 *)sg->tri_verts, (float4 *)woop_prim, (uint32_t *)sg->bad_flag);
         }
         uint32_t bad = 0;
         if (st == LPT_OK) {
@@ -831,6 +824,9 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
     { const int fst = flush_device(sg->dev); if (fst != LPT_OK) return fst; }
     HIP_TRY(hipDeviceSynchronize());
     uint32_t changed = 0;
+    // the re-baked triangles' Woop maps in prim order; a place-driven scatter then takes them to every place a triangle has in the tree (a split triangle has several)
+    void *woop_prim = nullptr;
+    const uint32_t n_places = kNodeTris * sg->stats.nodes;
     for (size_t i = 0; i < scene->instances.size(); ++i) {
         const lpt_instance &now = scene->instances[i];
         lpt_instance &was = sg->instances[i];
@@ -842,9 +838,11 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
             // re-bake on the device: the object-space mesh is resident, only the transform travels
             BakeArgs a;
             int bst = make_bake_args(sg, *scene, i, first, n, a);
-            if (bst != LPT_OK) return bst;
+            if (bst != LPT_OK) { if (woop_prim) hipFree(woop_prim); return bst; }
+            if (!woop_prim) HIP_TRY(hipMalloc(&woop_prim, sizeof(WoopTri) * (size_t)std::max(sg->stats.triangles, 1u)));
             hipLaunchKernelGGL(k_bake_instance, dim3(div_up(n, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
-                               (float4 *)sg->tri_verts, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, (uint32_t *)sg->bad_flag);
+                               (float4 *)sg->tri_verts, (float4 *)woop_prim, (uint32_t *)sg->bad_flag);
+            hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(n_places, 256u)), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)sg->leaf_prim, n_places, first, n);
         }
         was = now;
         ++changed;
@@ -853,6 +851,7 @@ int lpt_scene_gpu_update_instances(lpt_scene_gpu *sg, const lpt_scene *scene, ui
         uint32_t bad = 0;
         HIP_TRY(hipMemcpyAsync(&bad, sg->bad_flag, sizeof bad, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (woop_prim) { hipFree(woop_prim); woop_prim = nullptr; }
         if (bad) {
             HIP_TRY(hipMemsetAsync(sg->bad_flag, 0, sizeof bad, s));
             return fail(LPT_ERR_ACCEL_BUILD, "non-finite vertex in a re-baked instance");
@@ -898,7 +897,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
         int bst = make_bake_args(sg, *scene, i, first, cnt, a);
         if (bst != LPT_OK) { hipFree(woop_prim); return bst; }
         hipLaunchKernelGGL(k_bake_instance, dim3(div_up(cnt, 256u)), dim3(256), 0, s, a, (const float4 *)sg->obj_verts, (const uint32_t *)sg->obj_indices,
-                           (float4 *)sg->tri_verts, (float4 *)woop_prim, (const uint32_t *)nullptr, (uint32_t *)sg->bad_flag);
+                           (float4 *)sg->tri_verts, (float4 *)woop_prim, (uint32_t *)sg->bad_flag);
     }
     uint32_t bad = 0;
     hipError_t e = hipMemcpyAsync(&bad, sg->bad_flag, sizeof bad, hipMemcpyDeviceToHost, s);
@@ -910,19 +909,20 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
     }
     // build into NEW buffers and swap them in only on success: a failed build (out of memory, node budget) leaves the
     // scene exactly as it was, so bound renderers and later updates never see freed memory
-    void **slots[] = {&sg->nodes, &sg->woop, &sg->leaf_prim, &sg->tri_slot, &sg->node_lo, &sg->node_hi};
-    void *old[6];
-    for (int k = 0; k < 6; ++k) { old[k] = *slots[k]; *slots[k] = nullptr; }
+    void **slots[] = {&sg->nodes, &sg->woop, &sg->leaf_prim, &sg->node_lo, &sg->node_hi};
+    void *old[5];
+    for (int k = 0; k < 5; ++k) { old[k] = *slots[k]; *slots[k] = nullptr; }
     const DScene old_d = sg->d;
     const lpt_accel_stats old_stats = sg->stats;
     const std::vector<uint32_t> old_levels = sg->level_start;
     int st = build_lbvh(sg, n, nullptr, (const float4 *)woop_prim, s);
     if (st != LPT_OK) {
-        for (int k = 0; k < 6; ++k) { if (*slots[k]) hipFree(*slots[k]); *slots[k] = old[k]; }
+        for (int k = 0; k < 5; ++k) { if (*slots[k]) hipFree(*slots[k]); *slots[k] = old[k]; }
         sg->d = old_d; sg->stats = old_stats; sg->level_start = old_levels;
         // the shading records were re-baked in place: put the old tree back in step with them (new Woop maps into the
         // old leaf order, boxes refitted; topology kept)
-        hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(n, 256u)), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)sg->tri_slot, n);
+        hipLaunchKernelGGL(k_lbvh_scatter_woop, dim3(div_up(kNodeTris * sg->stats.nodes, 256u)), dim3(256), 0, s, (const float4 *)woop_prim, (float4 *)sg->woop, (const uint32_t *)sg->leaf_prim,
+                           kNodeTris * sg->stats.nodes, 0u, n);
         if (sg->stats.triangles) { float blo[3], bhi[3]; scene_bounds_and_grid(sg, n, s, blo, bhi, true); }   // (build_lbvh had set the NEW scene's grid in sg->d before old_d came back)
         if (sg->stats.triangles)
             for (size_t l = sg->level_start.size() - 1; l-- > 0;) {
@@ -935,7 +935,7 @@ int lpt_scene_gpu_rebuild(lpt_scene_gpu *sg, const lpt_scene *scene) {
         return st;
     }
     hipFree(woop_prim);
-    for (int k = 0; k < 6; ++k) if (old[k]) hipFree(old[k]);
+    for (int k = 0; k < 5; ++k) if (old[k]) hipFree(old[k]);
     sg->d.stack_entries = sg->stats.max_depth > 2u ? sg->stats.max_depth - 1u : 1u;
     sg->instances = scene->instances;
     return LPT_OK;

@@ -33,7 +33,7 @@ namespace {
 constexpr uint32_t kMagic = 0x4C504846u;   // "LPHF"
 struct Header { uint32_t magic, width, height, world, ready, pad[11]; };
 static_assert(sizeof(Header) == 64, "one line");
-struct alignas(64) Line { std::atomic<uint32_t> word; uint32_t pad[15]; };
+struct alignas(64) Line { std::atomic<uint32_t> word; std::atomic<uint32_t> note; uint32_t pad[14]; };   // note: line 0 only — rank 0's "I sleep on rank q's word" (q + 1; 0 = awake)
 static_assert(sizeof(Line) == 64, "one line");
 inline size_t frame_offset(uint32_t world) { return ((sizeof(Header) + sizeof(Line) * ((size_t)world + 1u)) + 4095u) & ~(size_t)4095u; }
 inline int futex(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec *ts) {
@@ -108,6 +108,17 @@ static int open_frame(const char *name, uint32_t width, uint32_t height, uint32_
     return LPT_OK;
 }
 
+// the spin loops' pause: the x86 hint, a yield on aarch64, a compiler barrier elsewhere
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
+
 extern "C" {
 
 int lpt_host_frame_create(const char *name, uint32_t width, uint32_t height, uint32_t world, uint32_t flags, lpt_host_frame **out) { return open_frame(name, width, height, world, flags, true, out); }
@@ -124,7 +135,7 @@ int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, 
     Line *ln = f->lines();
     std::atomic<uint32_t> &all = ln[f->world].word;
     // rank 0's "I sleep on word q" note, in its own line's padding: an arriving rank wakes it only then (no syscall per rank and frame in the normal case)
-    std::atomic<uint32_t> &sleeping_on = *reinterpret_cast<std::atomic<uint32_t> *>(&ln[0].pad[0]);   // 0 = awake, q + 1 = asleep on rank q's word
+    std::atomic<uint32_t> &sleeping_on = ln[0].note;   // 0 = awake, q + 1 = asleep on rank q's word
     ln[rank].word.store(frame_no, std::memory_order_seq_cst);
     if (rank != 0u && sleeping_on.load(std::memory_order_seq_cst) == rank + 1u) futex(&ln[rank].word, FUTEX_WAKE, 1, nullptr);
     const double t_end = now_ms() + (double)timeout_ms;
@@ -136,7 +147,7 @@ int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, 
             for (;;) {
                 uint32_t v = ln[q].word.load(std::memory_order_acquire);
                 if (reached(v)) break;
-                if (++spins < 20000u) { __builtin_ia32_pause(); continue; }
+                if (++spins < 20000u) { cpu_relax(); continue; }
                 const double left = t_end - now_ms();
                 if (left <= 0.0) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: rank %u did not reach frame %u within %u ms", q, frame_no, timeout_ms);
                 // sleep ON rank q's word: say so first, look again (the store / load pairs on both sides are sequentially consistent: either rank q sees the note
@@ -160,7 +171,7 @@ int lpt_host_frame_barrier(lpt_host_frame *f, uint32_t rank, uint32_t frame_no, 
     for (;;) {
         const uint32_t v = all.load(std::memory_order_acquire);
         if (reached(v)) return LPT_OK;
-        if (++spins < 20000u) { __builtin_ia32_pause(); continue; }
+        if (++spins < 20000u) { cpu_relax(); continue; }
         const double left = t_end - now_ms();
         if (left <= 0.0) return fail(LPT_ERR_READBACK, "failed to read pixels from GPU to CPU: frame %u was not completed within %u ms", frame_no, timeout_ms);
         timespec ts;

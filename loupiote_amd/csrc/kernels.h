@@ -2241,7 +2241,7 @@ __device__ __forceinline__ void woop_device(const float p0[3], const float p1[3]
 }
 
 __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 *obj_verts /* 2 float4 per vertex */, const uint32_t *indices,
-                                                       float4 *tri_verts, float4 *woop, const uint32_t *tri_slot, uint32_t *bad) {
+                                                       float4 *tri_verts, float4 *woop_prim, uint32_t *bad) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= a.n_tris) return;
     const float *m = a.m;
@@ -2270,8 +2270,9 @@ __global__ __launch_bounds__(256) void k_bake_instance(BakeArgs a, const float4 
     tri_verts[kTriRec * (size_t)(a.first_tri + t) + 7u] = a.mat[1];
     float4 w[3];
     woop_device(P[0], P[1], P[2], w);
-    const uint32_t slot = tri_slot ? tri_slot[a.first_tri + t] : a.first_tri + t;  // no slot table: prim order (full rebuild)
-    woop[3u * (size_t)slot] = w[0]; woop[3u * (size_t)slot + 1] = w[1]; woop[3u * (size_t)slot + 2] = w[2];
+    // prim order: k_lbvh_scatter_woop takes the maps to the triangle's place(s) in the tree (a split triangle has several)
+    const uint32_t slot = a.first_tri + t;
+    woop_prim[3u * (size_t)slot] = w[0]; woop_prim[3u * (size_t)slot + 1] = w[1]; woop_prim[3u * (size_t)slot + 2] = w[2];
 }
 
 }  // namespace lptd

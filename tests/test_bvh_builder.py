@@ -22,7 +22,7 @@ def bvh_check(tmp_path_factory):
     return exe
 
 
-def run(exe, tmp_path, tris, rays, mode=None, eye=None, reinsert=None):
+def run(exe, tmp_path, tris, rays, mode=None, eye=None, reinsert=None, split=None):
     path = str(tmp_path / "soup.bin")
     tris = np.ascontiguousarray(tris, "<f4").reshape(-1, 9)
     with open(path, "wb") as f:
@@ -33,6 +33,8 @@ def run(exe, tmp_path, tris, rays, mode=None, eye=None, reinsert=None):
         env["LPT_BVH_COLLAPSE"] = mode
     if reinsert is not None:
         env["LPT_BVH_REINSERT"] = reinsert
+    if split is not None:
+        env["LPT_BVH_SPLIT"] = split
     cmd = [exe, path, str(rays), "1"] + ([str(v) for v in eye] if eye else [])
     p = subprocess.run(cmd, env=env, capture_output=True, text=True)
     out = json.loads(p.stdout.strip().splitlines()[-1])
@@ -133,3 +135,33 @@ def test_grazing_rays_at_a_scale_ratio_of_a_million_lose_no_hit(bvh_check, tmp_p
     tris = np.concatenate([m["positions"][m["indices"]].reshape(-1, 9) for m in d["meshes"]])
     out = run(bvh_check, tmp_path, tris, 150000)
     assert out["triangles"] == 3002 and out["mismatches"] == 0 and out["bad_refs"] == 0 and out["hits"] > 10000, out
+
+
+def test_presplit_slivers_are_split_walls_are_not_and_no_hit_is_lost(bvh_check, tmp_path):
+    """round 6 (bvh.cpp presplit): triangles whose boxes are mostly EMPTY — long slivers across a cloud of small triangles — get several references (clipped boxes),
+    the rays test fewer triangles, and every random ray still finds exactly the brute-force closest hit (t and prim: the clipped boxes are conservative; a split
+    triangle is simply tested in more than one leaf); two-triangle axis-aligned walls, which fill their flat boxes, are left alone; so is a soup of evenly sized triangles"""
+    rng = np.random.default_rng(11)
+    small = random_soup(rng, 4000, extent=8.0, size=0.05)
+    a0 = rng.uniform(-8, 8, (60, 3)).astype(np.float32)
+    dirn = rng.normal(size=(60, 3)).astype(np.float32)
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    side = np.cross(dirn, rng.normal(size=(60, 3))).astype(np.float32)
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    slivers = np.stack([a0, a0 + dirn * 12.0, a0 + dirn * 6.0 + side * 0.01], axis=1).astype(np.float32)
+    soup = np.concatenate([small, slivers])
+    off = run(bvh_check, tmp_path, soup, 6000, split="1e30,0")
+    on = run(bvh_check, tmp_path, soup, 6000)
+    assert off["references"] == off["triangles"] == len(soup) and off["mismatches"] == 0
+    assert on["references"] > on["triangles"] == len(soup) and on["references"] <= 1.3 * len(soup) + 1
+    assert on["mismatches"] == 0 and on["bad_refs"] == 0
+    assert on["tris_per_ray"] < 0.8 * off["tris_per_ray"], (on, off)
+    # walls: two axis-aligned triangles per face around the same cloud — they fill their boxes, nothing to split
+    def quad(o, eu, ev):
+        o, eu, ev = (np.asarray(x, np.float32) for x in (o, eu, ev))
+        return [[o, o + eu, o + eu + ev], [o, o + eu + ev, o + ev]]
+    walls = np.asarray(quad((-9, -9, -9), (18, 0, 0), (0, 0, 18)) + quad((-9, -9, -9), (18, 0, 0), (0, 18, 0)) + quad((-9, -9, -9), (0, 18, 0), (0, 0, 18)), np.float32)
+    out = run(bvh_check, tmp_path, np.concatenate([small, walls]), 4000)
+    assert out["references"] == out["triangles"] and out["mismatches"] == 0
+    out = run(bvh_check, tmp_path, random_soup(rng, 3000), 3000)
+    assert out["references"] == out["triangles"] and out["mismatches"] == 0

@@ -11,6 +11,7 @@
 // usage: bvh_check <soup.bin> <n_rays> <brute:0|1> [ox oy oz]   (soup.bin: u32 n_tris, then 9 f32 per triangle)
 // With an origin the rays are a mix of camera-like rays from that point and random segment rays;
 // without, random segment rays inside the scene bounds.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,8 +42,10 @@ bool ray_tri(const WoopTri &w, const float o[3], const float d[3], float tmax, f
     return true;
 }
 
+std::vector<uint32_t> g_tests;   // BVH_CHECK_TOP: tests per baked triangle (which triangles a tree makes the rays test again and again)
 void consider(const Accel &a, uint32_t ti, const float o[3], const float d[3], Hit &best) {
     float t;
+    if (!g_tests.empty() && a.leaf_prim[ti] < g_tests.size()) g_tests[a.leaf_prim[ti]]++;
     if (ray_tri(a.woop[ti], o, d, best.t, t)) {
         const uint32_t prim = a.leaf_prim[ti];
         if (t < best.t || prim < best.prim) { best.t = t; best.prim = prim; }
@@ -143,9 +146,10 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> seen(n_baked, 0);
     size_t bad_refs = 0;
     if (n_baked)
-        for (uint32_t p : acc.leaf_prim) { if (p == LPT_INVALID_INDEX) continue; if (p >= n_baked || seen[p]++) bad_refs++; }   // holes: unused triangle places
+        for (uint32_t p : acc.leaf_prim) { if (p == LPT_INVALID_INDEX) continue; if (p >= n_baked) bad_refs++; else if (seen[p] < 255) seen[p]++; }   // holes: unused places; a split triangle (bvh.cpp presplit) has several
     for (size_t i = 0; i < n_baked; ++i) if (!seen[i]) bad_refs++;
 
+    if (getenv("BVH_CHECK_TOP")) g_tests.assign(n_baked, 0u);
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < pos.size(); ++i) { lo[i % 3] = std::min(lo[i % 3], pos[i]); hi[i % 3] = std::max(hi[i % 3], pos[i]); }
     if (!n) { lo[0] = lo[1] = lo[2] = -1; hi[0] = hi[1] = hi[2] = 1; }
@@ -180,9 +184,33 @@ int main(int argc, char **argv) {
             if (b.prim != h.prim || b.t != h.t) mismatches++;
         }
     }
-    printf("{\"triangles\": %zu, \"nodes\": %zu, \"depth\": %u, \"bad_refs\": %zu, \"rays\": %d, \"hits\": %zu, \"mismatches\": %zu, "
+    if (!g_tests.empty()) {
+        std::vector<uint32_t> order(g_tests.size());
+        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g_tests[x] > g_tests[y]; });
+        unsigned long long total = 0, top = 0;
+        for (uint32_t c : g_tests) total += c;
+        for (int k = 0; k < 20 && k < (int)order.size(); ++k) {
+            const uint32_t pr = order[k];
+            const lpt_vertex *v = &acc.tri_verts[3 * (size_t)pr];
+            float lo3[3] = {1e30f, 1e30f, 1e30f}, hi3[3] = {-1e30f, -1e30f, -1e30f};
+            for (int q = 0; q < 3; ++q) for (int a2 = 0; a2 < 3; ++a2) { lo3[a2] = std::min(lo3[a2], v[q].position[a2]); hi3[a2] = std::max(hi3[a2], v[q].position[a2]); }
+            top += g_tests[pr];
+            fprintf(stderr, "top %2d: prim %u tested %u times, box extent %.3f x %.3f x %.3f at (%.2f, %.2f, %.2f)\n", k, pr, g_tests[pr], hi3[0] - lo3[0], hi3[1] - lo3[1], hi3[2] - lo3[2], lo3[0], lo3[1], lo3[2]);
+        }
+        fprintf(stderr, "top 20 triangles: %llu of %llu tests\n", top, total);
+        for (int dch = 0; dch < 20; ++dch) {
+            unsigned long long part = 0;
+            const size_t a0 = g_tests.size() * dch / 20, a1 = g_tests.size() * (dch + 1) / 20;
+            for (size_t i = a0; i < a1; ++i) part += g_tests[i];
+            fprintf(stderr, "prims [%zu, %zu): %llu tests\n", a0, a1, part);
+        }
+    }
+    size_t n_refs = 0;
+    for (uint32_t p : acc.leaf_prim) n_refs += p != LPT_INVALID_INDEX;
+    printf("{\"triangles\": %zu, \"references\": %zu, \"nodes\": %zu, \"depth\": %u, \"bad_refs\": %zu, \"rays\": %d, \"hits\": %zu, \"mismatches\": %zu, "
            "\"nodes_per_ray\": %.4f, \"tris_per_ray\": %.4f, \"max_stack_depth\": %u, \"build_ms\": %.1f}\n",
-           n_baked, acc.nodes.size(), acc.max_depth, bad_refs, n_rays, hits, mismatches, (double)st.nodes / std::max(n_rays, 1),
+           n_baked, n_refs, acc.nodes.size(), acc.max_depth, bad_refs, n_rays, hits, mismatches, (double)st.nodes / std::max(n_rays, 1),
            (double)st.tris / std::max(n_rays, 1), st.max_stack, acc.build_ms);
     lpt_scene_destroy(scene);
     return (bad_refs || mismatches) ? 1 : 0;

@@ -14,7 +14,16 @@ import loupiote_amd as lp  # noqa: E402
 from loupiote_amd import scenes, testing as T  # noqa: E402
 
 
-def measure(dev, name, scene, probe, cam, w, h, spp, depth, frames=12, warm=3, mode=lp.BlitMode.Pahtrace, pipeline=3):
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # substrings of the config names to run (default: all)
+
+
+def measure(dev, name, scene, probe, cam, w, h, spp, depth, frames=12, warm=3, mode=lp.BlitMode.Pahtrace, pipeline=3, stats=False, shard=None):
+    if ONLY and not any(o in name for o in ONLY):
+        return
+    if callable(scene):
+        scene = scene()
+    """stats: one more frame with the stats kernels — 8-wide nodes visited / triangles tested per ray of the per-ray traversal launches (what a builder's tree costs on
+    this triangle distribution).  shard = (rank, world): that rank's tile shard of the frame alone (strong scaling of one frame, emulated on one GPU)."""
     sg = lp.SceneGPU.new_from_scene(scene, dev)
     pr = lp.ProbeGPU(dev, probe, probe.shape[1], probe.shape[0])
     view = T.look(*cam)
@@ -26,6 +35,9 @@ def measure(dev, name, scene, probe, cam, w, h, spp, depth, frames=12, warm=3, m
         r.set_max_bounces(depth)
         r.set_vfov(T.VFOV)
         r.set_blit_mode(mode)
+        if shard:
+            r.set_shard(shard[0], shard[1], 32, 8)
+            r.set_resources(dev, sg, pr)
         rs.append(r)
 
     def step(k):
@@ -51,7 +63,21 @@ def measure(dev, name, scene, probe, cam, w, h, spp, depth, frames=12, warm=3, m
         if dt is None or d1 < dt:
             dt, rays = d1, sum(r.ray_counts().closest + r.ray_counts().shadow for r in rs)
     out = {"config": name, "size": [w, h], "spp": spp, "depth": depth, "ms_per_frame": dt / frames * 1e3, "Mrays_per_s": rays / dt / 1e6,
-           "triangles": sg.stats().triangles, "frames_in_flight": pipeline}
+           "triangles": sg.stats().triangles, "nodes": sg.stats().nodes, "tree_depth": sg.stats().max_depth, "frames_in_flight": pipeline}
+    if shard:
+        out["shard"] = list(shard)
+    if stats:
+        r = rs[0]
+        r.synchronize()
+        r.enable_stats(True)
+        r.reset_ray_counts()
+        step(0)
+        r.synchronize()
+        c = r.ray_counts()
+        r.enable_stats(False)
+        per_ray = max(c.closest - c.primary, 1)
+        out.update({"nodes_per_ray": c.nodes / per_ray, "tris_per_ray": c.tris / per_ray, "shadow_nodes_per_ray": c.shadow_nodes / max(c.shadow, 1),
+                    "shadow_tris_per_ray": c.shadow_tris / max(c.shadow, 1), "rays_per_frame": c.closest + c.shadow})
     for r in rs:
         r.close()
     pr.close(); sg.close()
@@ -70,12 +96,23 @@ def main():
     d = scenes.synthetic_atrium()
     sc = scenes.to_product(d)
     cam = (d["camera"]["origin"], d["camera"]["direction"])
-    measure(dev, "4: synthetic_atrium 1920x1080 4spp depth 8 (the bench line)", sc, d["probe"], cam, 1920, 1080, 4, 8)
+    measure(dev, "4: synthetic_atrium 1920x1080 4spp depth 8 (the bench line)", sc, d["probe"], cam, 1920, 1080, 4, 8, stats=True)
     measure(dev, "tiny: synthetic_atrium 64x36 4spp depth 8, frames back to back on one renderer, no read-back (a wave per ray, LPT_OPT_COOP_RAYS)", sc, d["probe"], cam, 64, 36, 4, 8, frames=40, pipeline=1)
     measure(dev, "small: synthetic_atrium 384x216 4spp depth 8, frames back to back on one renderer, no read-back (per-bounce launches, tails in place)", sc, d["probe"], cam, 384, 216, 4, 8, frames=40, pipeline=1)
     measure(dev, "5a: synthetic_atrium 3840x2160 64spp progressive (8 x raytrace_n(8)) depth 8", sc, d["probe"], cam, 3840, 2160, 8, 8, frames=8, warm=2, pipeline=2)
     measure(dev, "5b: synthetic_atrium 3840x2160 temporal accumulate, 1 spp per frame, depth 8", sc, d["probe"], cam, 3840, 2160, 1, 8, frames=16, warm=3,
             mode=lp.BlitMode.Temporal, pipeline=1)
+    # config 5 across GPUs, emulated — rank 0's 1/8 tile shard of the 64-spp 4K frame alone (fused wavefronts of up to 64 samples): against 5a's whole
+    # frame this is the strong scaling 8 GPUs can give before any exchange
+    measure(dev, "5a whole, one renderer: synthetic_atrium 3840x2160 64spp (8 x raytrace_n(8)) depth 8", sc, d["probe"], cam, 3840, 2160, 8, 8, frames=8, warm=2, pipeline=1)
+    measure(dev, "5a shard 1/8 (rank 0 of 8), one renderer: the same frame's tile shard alone", sc, d["probe"], cam, 3840, 2160, 8, 8, frames=8, warm=2, pipeline=1, shard=(0, 8))
+    # Sponza-shaped triangle distributions (the stand-in's triangles are uniformly small): nodes / triangles per ray and the frame time
+    dq = scenes.synthetic_atrium(shell_quads=True)
+    measure(dev, "hall_large: synthetic_atrium(shell_quads=True) — floor / walls / roof as two triangles each — 1920x1080 4spp depth 8", scenes.to_product(dq), dq["probe"],
+            (dq["camera"]["origin"], dq["camera"]["direction"]), 1920, 1080, 4, 8, stats=True)
+    dh = scenes.synthetic_hall()
+    measure(dev, "hall: synthetic_hall (two-triangle walls around centimetre gravel, slivers, coincident quads, a telescope) 1920x1080 4spp depth 8", scenes.to_product(dh), dh["probe"],
+            (dh["camera"]["origin"], dh["camera"]["direction"]), 1920, 1080, 4, 8, stats=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """dev: the bench scene's world-space triangle soup as tests/tools/bvh_check's input (offline BVH-quality runs on the CPU)
-usage: python tools/dev/dump_soup.py out.bin [atrium|helmet]"""
+usage: python tools/dev/dump_soup.py out.bin [atrium|atrium_quads|hall|helmet]"""
 import struct
 import sys
 
@@ -9,7 +9,8 @@ sys.path.insert(0, ".")
 from loupiote_amd import scenes
 
 which = sys.argv[2] if len(sys.argv) > 2 else "atrium"
-desc = scenes.synthetic_atrium(textures=False) if which == "atrium" else scenes.synthetic_helmet(textures=False)
+desc = {"atrium": lambda: scenes.synthetic_atrium(textures=False), "atrium_quads": lambda: scenes.synthetic_atrium(textures=False, shell_quads=True),
+        "hall": scenes.synthetic_hall, "helmet": lambda: scenes.synthetic_helmet(textures=False)}[which]()
 tris = []
 for blas, m, _mat in desc["instances"]:
     mesh = desc["meshes"][blas - 1]                      # BLAS index in the final scene: the dummy entry 0 precedes
