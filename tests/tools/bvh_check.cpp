@@ -55,6 +55,7 @@ void consider(const Accel &a, uint32_t ti, const float o[3], const float d[3], H
 float safe_inv(float d) { return fabsf(d) > 1.0e-30f ? 1.0f / d : copysignf(1.0e30f, d); }
 
 struct Stats { uint64_t nodes = 0, tris = 0; uint32_t max_stack = 0; };
+bool near_first = false;   // BVH_CHECK_ORDER=near1
 bool by_distance = false;  // BVH_CHECK_ORDER=dist: visit inner children nearest first (bound on what ordering can save)
 
 Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
@@ -84,6 +85,7 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
         // visit order: kernels.h takes hit bits from the top, bit = 24 + (slot ^ oinv)
         struct Child { uint32_t key, node; };
         Child inner[8];
+        float inner_tn[8];
         int n_inner = 0;
         uint32_t rel = 0;
         for (int sl = 0; sl < 8; ++sl) {
@@ -99,11 +101,16 @@ Hit walk(const Accel &a, const float o[3], const float d[3], Stats &st) {
                 tf = fminf(tf, fmaf(qf, af[k], bf[k]));
             }
             if (!(tn <= tf)) continue;
-            if (is_inner) inner[n_inner++] = {by_distance ? ~__builtin_bit_cast(uint32_t, tn) : ((uint32_t)sl ^ oinv), n.child_base + my_rel};
+            if (is_inner) { inner_tn[n_inner] = tn; inner[n_inner++] = {by_distance ? ~__builtin_bit_cast(uint32_t, tn) : ((uint32_t)sl ^ oinv), n.child_base + my_rel}; }
             else {
                 const uint32_t cnt = 1u + ((n.leaf2 >> sl) & 1u);
                 for (uint32_t k = 0; k < cnt; ++k) { st.tris++; consider(a, e.node * kNodeTris + 2u * (uint32_t)sl + k, o, d, best); }
             }
+        }
+        if (near_first && n_inner > 1) {   // BVH_CHECK_ORDER=near1: the child entered first goes first, the others keep the octant order
+            int bi = 0;
+            for (int i = 1; i < n_inner; ++i) if (inner_tn[i] < inner_tn[bi]) bi = i;
+            inner[bi].key = 0xFFFFFFFFu;
         }
         // push so that the largest key pops first
         for (int i = 0; i < n_inner; ++i)
@@ -127,6 +134,7 @@ int main(int argc, char **argv) {
     if (n && fread(pos.data(), 4, pos.size(), f) != pos.size()) return 2;
     fclose(f);
     by_distance = getenv("BVH_CHECK_ORDER") && !strcmp(getenv("BVH_CHECK_ORDER"), "dist");
+    near_first = getenv("BVH_CHECK_ORDER") && !strcmp(getenv("BVH_CHECK_ORDER"), "near1");
     const int n_rays = atoi(argv[2]);
     const bool brute = atoi(argv[3]) != 0;
 
