@@ -77,6 +77,8 @@ def parse_args(argv=None):
                          "headline cannot be lost to RCCL code that has never run with N > 1.  gather: owned tiles only (W*H/N*16 B per rank, grouped send/recv), reduce: the dense ncclReduce of the accumulation buffer, or "
                          "`host`: no exchange on the GPUs — every rank writes its owned pixels straight into ONE shared-memory frame (lpt_renderer_read_radiance_owned; "
                          "each GPU's 1/N over its own PCIe link), completed by a host-side barrier")
+    ap.add_argument("--rccl-timeout", type=float, default=60.0, help="--exchange auto: seconds the RCCL bring-up (ncclCommInitRank on every rank) may take before the run continues RCCL-free; "
+                    "a calibration leg gets 1.5 x this")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N>1: skip the legs that time the two exchange forms the timed region did not use (tests that do not look at them)")
     ap.add_argument("--pipeline", type=int, default=0, help="renderers in flight of the `throughput` measurement (each with its own HIP stream and, for N>1, its own "
                     "RCCL communicator); default 3 on one GPU, 4 for tile shards")
@@ -424,11 +426,11 @@ def run(args):
         # the operations of ONE communicator, so frames in flight must not share one
         n_comms = 1 + (P if tp_leg else 0)
         if auto:
-            ids, rccl_error = in_watchdog(lambda: [lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None, 30.0, "ncclGetUniqueId")
+            ids, rccl_error = in_watchdog(lambda: [lp.Comm.unique_id() for _ in range(n_comms)] if rank == 0 else None, 0.5 * args.rccl_timeout, "ncclGetUniqueId")
             if rccl_error is None:
                 box = [ids]
                 dist.broadcast_object_list(box, src=0)
-                got, rccl_error = in_watchdog(lambda: [lp.Comm(dev, uid, rank, world) for uid in box[0]], 60.0, "ncclCommInitRank")
+                got, rccl_error = in_watchdog(lambda: [lp.Comm(dev, uid, rank, world) for uid in box[0]], args.rccl_timeout, "ncclCommInitRank")
                 if rccl_error is None:
                     comms = got
             if rccl_error is not None and args.blit_mode != "pathtrace":
@@ -584,7 +586,7 @@ def run(args):
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
                 rr.close()
                 return float(dt.item()) / 5 * 1e3
-            ms, err = in_watchdog(leg, 90.0, "calibration of the %s form" % form)
+            ms, err = in_watchdog(leg, 1.5 * args.rccl_timeout, "calibration of the %s form" % form)
             if err is None:
                 exchange_auto["calibration_ms_per_frame"][form] = ms
             else:
