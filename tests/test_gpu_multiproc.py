@@ -48,8 +48,18 @@ def _bench(extra, env_extra=None):
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
 
 
+_ONE = {}
+
+
+def _one():
+    """the one-process line every N>1 test compares its frame with: run once per session"""
+    if "j" not in _ONE:
+        _ONE["j"] = _bench(["--no-extras"])
+    return _ONE["j"]
+
+
 def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
-    one = _bench(["--no-extras"])
+    one = _one()
     assert one["n_gpus"] == 1 and one["config"]["frame_complete"] is True
     for n, mode in ((2, "gather"), (3, "reduce"), (3, "gather")):
         j = _bench(["--gpus", str(n), "--oversubscribe", "--root-weight", "8", "--exchange", mode, "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
@@ -65,7 +75,7 @@ def test_self_started_ranks_exchange_the_single_gpu_frame(fake_rccl):
 def test_the_drivers_launcher_command_line(fake_rccl):
     """the contract's N>1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` —
     the ranks come from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), bench.py starts none itself; rank 0 prints the one JSON line"""
-    one = _bench(["--no-extras"])
+    one = _one()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["LPT_RCCL_LIBRARY"] = fake_rccl
     import socket
@@ -89,7 +99,7 @@ def test_exchange_inside_a_group_bracket_and_the_denoising_modes_across_processe
     so a second phase (unpack) enqueued too early would read stale tiles and the checksum would differ.  (ii) BlitMode::Temporal across two
     processes (BASELINE config 5's form): the filter inputs travel after every call, rank 0 filters, its tile weight is calibrated with
     the filter in the frame (VERDICT r03 #4 iv) — the presented frame equals the one-process frame bit for bit."""
-    one = _bench(["--no-extras"])
+    one = _one()
     j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--exchange", "gather", "--group-bracket", "--no-extras"] + NOXF, {"LPT_RCCL_LIBRARY": fake_rccl})
     assert j["rccl"]["exchange_frame_complete_on_rank0"] is True and j["config"]["frame_checksum"] == one["config"]["frame_checksum"]
     t1 = _bench(["--blit-mode", "temporal", "--no-extras", "--no-shard-emulation"])
@@ -105,7 +115,7 @@ def test_host_side_gather_across_processes():
     (lpt_host_frame_create / _attach, lpt_renderer_read_radiance_owned, lpt_host_frame_barrier: shm + hipHostRegister + progress words, no Python in the protocol);
     the frame is the one-process frame bit for bit.  (Without the stand-in the extra RCCL legs of `exchange_forms` fail — real RCCL refuses two ranks on one
     GPU — and are reported as errors: they must not take the line down.)"""
-    one = _bench(["--no-extras"])
+    one = _one()
     for n in (2, 3):
         j = _bench(["--gpus", str(n), "--oversubscribe", "--exchange", "host", "--no-extras"] + (NOXF if n == 3 else []))
         assert j["n_gpus"] == n and j["rccl"] is None and j["host_gather"]["frame_complete_on_rank0"] is True and j["host_gather"]["ranks"] == n
@@ -160,7 +170,7 @@ def test_a_missing_rccl_library_is_a_loud_error():
 def test_exchange_auto_picks_the_fastest_form_that_came_up(fake_rccl):
     """`--exchange auto` (the default for N > 1): RCCL comes up under a watchdog, every form gets calibration frames, the timed region uses the
     fastest — and the line says which, with all three forms still reported and their checksums equal"""
-    one = _bench(["--no-extras"])
+    one = _one()
     j = _bench(["--gpus", "2", "--oversubscribe", "--root-weight", "8", "--no-extras"], {"LPT_RCCL_LIBRARY": fake_rccl})     # no --exchange: auto
     ea = j["exchange_auto"]
     assert set(ea["calibration_ms_per_frame"]) == {"host", "gather", "reduce"} and not ea["errors"], ea
@@ -177,7 +187,7 @@ def test_exchange_auto_survives_an_rccl_bring_up_that_never_returns(fake_rccl):
     """the stand-in's ncclCommInitRank blocks forever (FAKE_RCCL_HANG_INIT): after the watchdog's time (60 s by default, 8 here) the run continues RCCL-free — the line appears, its frame is
     the one-process frame, `config.exchange` says host, `rccl.error` says why, the RCCL forms are reported as errors; the stuck thread is abandoned, nothing is
     restarted and the process leaves with status 0"""
-    one = _bench(["--no-extras"])
+    one = _one()
     j = _bench(["--gpus", "2", "--oversubscribe", "--no-extras", "--rccl-timeout", "8"], {"LPT_RCCL_LIBRARY": fake_rccl, "FAKE_RCCL_HANG_INIT": "1"})
     assert j["n_gpus"] == 2 and j["config"]["exchange"].startswith("host")
     assert "ncclCommInitRank did not return" in j["rccl"]["error"]
