@@ -1698,11 +1698,11 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
         const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
-        // the one-round-trip step (kernels.h ray_step_pipe): 78 VGPRs, so 6 waves per SIMD instead of 8, ~3 % more nodes and ~12 % more
+        // the one-round-trip step (kernels.h ray_step_pipe): 72 VGPRs (round 6; 78 before), 6 waves per SIMD used of the 7 that fit, ~3 % more nodes and ~12 % more
         // triangles fetched per ray — and still 1 % less time per frame at 8 M rays, 2 % for a 1 M-ray tile shard
         // (profiles/r03_experiments_ab.txt); LPT_EXP_PIPE_RAYS 0 selects the two-round-trip step
         const bool pipe = n_rays <= r->pipe_rays;
-        // persistent waves: about 2.5 primary rays per lane, between 8 waves per CU and all that fit (24 at 78 VGPRs, 32 at 59).  A 1/8
+        // persistent waves: about 2.5 primary rays per lane, between 8 waves per CU and all that fit (24 = 6 per SIMD with the one-round-trip step — 28 measured no faster, round 6 —, 32 with the other).  A 1/8
         // tile shard (1 M rays per launch) is best at 24 either way (round 3, span form, two-round-trip step: 8 / 12 / 16 / 24 / 32
         // waves per CU -> 4.41 / 3.89 / 3.62 / 3.51 / 3.54 ms per frame)
         uint32_t waves = r->trace_waves_per_cu ? cus * r->trace_waves_per_cu : std::min(std::max(n_rays / 160u, cus * 8u), cus * (pipe ? 24u : 32u));

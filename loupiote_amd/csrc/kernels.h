@@ -532,9 +532,10 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
 // The same step with ONE memory round trip instead of two: the triangle tested in a step is one that an EARLIER step found, so its
 // fetch is issued together with this step's node fetch instead of behind the node test; a lane visits a node in every step in
 // which it has one and room for what the visit may find (rs.tg2).  The triangle tests lag the node visits by a step, so the best
-// hit shrinks a little later: ~3 % more nodes and ~12 % more triangles are fetched per ray, and the three triangle rows stay live
-// across the node test (78 VGPRs: 6 waves per SIMD instead of 8) — and the launch is still 1-3 % shorter at every size measured
-// (DESIGN §5.1).  The host picks the variant per wavefront (device.hip: pipe_rays); the default is this one.
+// hit shrinks a little later: ~3 % more nodes and ~12 % more triangles are fetched per ray — and the launch is still 1-3 % shorter at
+// every size measured.  Round 6: within the step the fetched triangle is tested BEFORE the node's children (its rows are dead by
+// then: 72 VGPRs where the other order needed 78-79, and the children are tested against the hit it may have found).
+// The host picks the variant per wavefront (device.hip: pipe_rays); the default is this one.
 template <bool STATS>
 __device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris) {
     const bool node_work = (rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0;
@@ -779,7 +780,7 @@ __device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3
 // cooperative walk above, the triangle groups the lane still holds are tested first, the best hit so far carries over.  Nothing is restarted at the root and
 // no second launch is needed (the step budget + k_trace_coop pair this replaces: 48 steps thrown away per straggler, ~19 us of launch per bounce).
 // `columns` = the wave's per-lane stacks (entry e of lane L at columns[e * kTraceBlock + L]); `tail_lds` = tail_lds_words(depth) words behind them: the live
-// rays' states first (parked there so that the per-lane state's registers are free during the walks: 80 VGPRs, still 6 waves per SIMD), then the node column.
+// rays' states first (parked there so that the walk behind the loop starts from LDS, not from the loop's registers: 74 VGPRs, 6 waves per SIMD), then the node column.
 constexpr uint32_t kTailMax = 8u;          // rays a wave finishes this way at most (one after the other: beyond a handful the per-lane steps are faster)
 constexpr uint32_t kTailStateWords = 20u;  // five 16-byte rows per ray
 __host__ __device__ __forceinline__ uint32_t tail_lds_words(uint32_t tree_depth) { return kTailMax * kTailStateWords + coop_stack_entries(kTailStack, tree_depth); }
