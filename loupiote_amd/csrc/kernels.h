@@ -449,7 +449,8 @@ __device__ __forceinline__ void node_fetch(const DScene &sc, RayState &rs, uint2
     nr.n0 = n->n0; nr.n2 = n->n2; nr.n3 = n->n3; nr.n4 = n->n4;
     if (STATS) n_nodes++;
 }
-__device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const NodeRows &nr) {
+// `lut` (LDS, xor_permute8_lut below) or nullptr (the delta swaps)
+__device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const NodeRows &nr, const uint8_t *lut = nullptr) {
     {
         const uint4 n0 = nr.n0, n2 = nr.n2, n3 = nr.n3, n4 = nr.n4;
         const uint32_t node_index = nr.index;
@@ -493,14 +494,18 @@ __device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const
         }
         // empty slots have inverted boxes; should the widening ever let one pass, it is in neither mask below
         const uint32_t imask = node_imask(n0), V = node_leaves(n0);
-        rs.ng = make_uint2(n0.w, (xor_permute8(h & imask, rs.oinv) << 24) | imask);
+        // the inner hits into visit order (slot XOR ray octant): two lookups in a 128-byte LDS table where the kernel set one up (k_trace's throughput variant: -2.5 % of
+        // the launch against the delta swaps), else three delta swaps (18 VALU instructions, no memory round trip: what a drain of dependent steps wants)
+        const uint32_t hin = h & imask;
+        const uint32_t hp = lut ? ((uint32_t)lut[(rs.oinv << 4) | (hin & 15u)] | (uint32_t)lut[((rs.oinv ^ 4u) << 4) | (hin >> 4)]) : xor_permute8(hin, rs.oinv);
+        rs.ng = make_uint2(n0.w, (hp << 24) | imask);
         return make_uint2(node_index * kNodeTris, (h | (h << 8)) & V);
     }
 }
 
 // returns true when the ray is finished (ANY: also as soon as something is hit; best.prim != ~0 then)
 template <bool STATS>
-__device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris) {
+__device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris, const uint8_t *lut = nullptr) {
     if (rs.tg.y == 0u) {
         if (!(rs.ng.y & 0xFF000000u)) {
             if (rs.sp == 0) return true;
@@ -509,7 +514,7 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
         }
         NodeRows nr;
         node_fetch<STATS>(sc, rs, stack, n_nodes, nr);
-        rs.tg = node_test(sc, rs, nr);
+        rs.tg = node_test(sc, rs, nr, lut);
     }
     if (rs.tg.y != 0u) {
         const uint32_t ti = tg_pop(rs.tg);
@@ -537,7 +542,7 @@ __device__ __forceinline__ bool ray_step_any(const DScene &sc, RayState &rs, uin
 // then: 72 VGPRs where the other order needed 78-79, and the children are tested against the hit it may have found).
 // The host picks the variant per wavefront (device.hip: pipe_rays); the default is this one.
 template <bool STATS>
-__device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris) {
+__device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, uint2 *stack, const bool ANY, uint32_t &n_nodes, uint32_t &n_tris, const uint8_t *lut = nullptr) {
     const bool node_work = (rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0;
     const bool tri_work = (rs.tg.y != 0u);      // rs.tg2 is only ever occupied while rs.tg is
     if (!node_work && !tri_work) return true;
@@ -570,7 +575,7 @@ __device__ __forceinline__ bool ray_step_pipe(const DScene &sc, RayState &rs, ui
         }
     }
     uint2 found = make_uint2(0u, 0u);
-    if (visit) found = node_test(sc, rs, nr);
+    if (visit) found = node_test(sc, rs, nr, lut);
     if (rs.tg.y == 0u) { rs.tg = rs.tg2; rs.tg2.y = 0u; }
     if (found.y != 0u) { if (rs.tg.y == 0u) rs.tg = found; else rs.tg2 = found; }
     return false;
@@ -892,6 +897,20 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
     uint32_t my_steps = 0;                                    // traversal steps of the ray in hand (STATS; the step budget)
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(lds_dyn + sc.stack_entries * kTraceBlock * sizeof(uint2));   // STATS: 12 buckets + the maximum, behind the stacks (host: + 64 B)
     if (STATS) { if (threadIdx.x < 16u) s_hist[threadIdx.x] = 0u; __syncthreads(); }
+    const uint8_t *lut = nullptr;
+    // the 8-bit XOR permutation of node_test as two table lookups: perm[o][nibble] = the low four slots' bits moved to slot ^ o (the high four: perm[o ^ 4]).  Not in
+    // the TAIL variant: a shard-sized launch is a drain of dependent steps, and two LDS round trips per step cost it more than the 18 VALU instructions they replace
+    if (!TAIL) {
+        __shared__ uint8_t s_perm[128];
+        for (uint32_t e = threadIdx.x; e < 128u; e += kTraceBlock) {
+            const uint32_t o = e >> 4, nib = e & 15u;
+            uint32_t v = 0u;
+            for (uint32_t sl = 0; sl < 4u; ++sl) if ((nib >> sl) & 1u) v |= 1u << (sl ^ o);
+            s_perm[e] = (uint8_t)v;
+        }
+        __syncthreads();
+        lut = s_perm;
+    }
     RayState rs;
     bool active = false, finished = false, shadow = false;
     uint32_t ray = 0;
@@ -967,7 +986,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
             w_node += (uint32_t)__popcll(__ballot(PIPE ? active && (rs.tg2.y == 0u) && ((rs.ng.y & 0xFF000000u) != 0u || rs.sp != 0) : active && (rs.tg.y == 0u)));
         }
         if ((STATS || budget) && active) my_steps++;
-        if (active && (PIPE ? ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt) : ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt))) {
+        if (active && (PIPE ? ray_step_pipe<STATS>(sc, rs, stack, shadow, dn, dt, lut) : ray_step_any<STATS>(sc, rs, stack, shadow, dn, dt, lut))) {
             active = false;
             finished = true;
         }
