@@ -413,9 +413,9 @@ Box padded_box(const lpt_vertex *v, float pad_abs) {
     return b;
 }
 
-// ---- TRIANGLE PRE-SPLITTING (round 6).  A triangle much larger than its neighbours — a wall of two triangles around finely tessellated
-// ornaments, a long sliver across the hall — drags its whole bounding box through the tree: on the bench scene with its shell as two-triangle quads a ray tested 22.4
-// triangles instead of 4.3 and the frame took 32.8 ms instead of 10.4 (profiles/r06a_configs_timing.jsonl).  Before the build, the LARGEST references are split at the
+// ---- TRIANGLE PRE-SPLITTING (round 6).  A triangle whose bounding box is mostly EMPTY — a long sliver across the hall — drags that box through the
+// tree: in the mixed-scale hall (scenes.synthetic_hall) a ray tested 28.1 triangles for its 14.7 nodes and the frame took 21.0 ms (profiles/r06b_configs_timing.jsonl,
+// profiles/r06_experiments_ab.txt E).  Before the build, the LARGEST references are split at the
 // middle of their box's longest axis — the triangle clipped against both halves (Sutherland-Hodgman, binary64), each half's box = the clipped polygon's, padded like a
 // triangle's — until no reference's EMPTY box area (below) exceeds kSplitRatio times the mean box area, or the budget of kSplitBudget extra references per triangle is
 // spent.  What is split is decided by emptiness, not size: a ray enters a box in proportion to its surface and hits the triangle in proportion to its area, so
