@@ -62,7 +62,9 @@ constexpr uint32_t kNodeTris = 16;   // triangle places per node
 inline void scene_grid(const float lo[3], const float hi[3], float grid_lo[3], float grid_step[3]) {
     for (int a = 0; a < 3; ++a) {
         const double m = std::fmax(std::fabs((double)lo[a]), std::fabs((double)hi[a]));
-        const double ext = std::fmax((double)hi[a] - (double)lo[a], std::fmax(m * 1e-5, 1e-30));
+        // never narrower than 1e-4 of the largest |coordinate|: the slack around the scene (a quarter of this) must exceed the triangle padding (6e-6 of that coordinate,
+        // bvh.cpp padded_box) even for a scene that is a speck far from the origin — a node's padded box must not reach below the grid
+        const double ext = std::fmax((double)hi[a] - (double)lo[a], std::fmax(m * 1e-4, 1e-30));
         int k;
         std::frexp(1.5 * ext / 65535.0, &k);                    // 1.5 ext / 65535 = f * 2^k, f in [0.5, 1)  =>  2^k is above it
         k = k < -120 ? -120 : (k > 100 ? 100 : k);

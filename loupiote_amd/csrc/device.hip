@@ -329,8 +329,8 @@ static int upload(void **dst, const T *src, size_t count, hipStream_t s) {
 // already on the device (sg->d.tri_verts).  `woop_prim` = the Woop maps in prim order (host, SPEC §6).
 // `host_woop`: the Woop maps in prim order on the host (upload path) or nullptr when `dev_woop` (device, prim order) is given.
 // Scene bounds from the baked triangles on the device (blocking), and what follows from them for every kernel that pads a triangle or writes a node: the scene-wide part
-// of the triangle padding (bvh.cpp padded_box; it never shrinks — a pad a little too wide costs nothing) and the scene grid of the node origins (common.h scene_grid; the
-// padding is far inside the grid's slack).  Before a build and before every refit.
+// of the triangle padding (bvh.cpp padded_box; it never shrinks — a pad a little too wide costs nothing) and the scene grid of the node origins (common.h scene_grid, of the
+// bounds widened by that padding).  Before a build and before every refit.
 static int scene_bounds_and_grid(lpt_scene_gpu *sg, uint32_t n, hipStream_t s, float blo[3], float bhi[3], bool keep_pad) {
     int *db = nullptr, hb[6];
     const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -345,7 +345,15 @@ static int scene_bounds_and_grid(lpt_scene_gpu *sg, uint32_t n, hipStream_t s, f
     for (int a = 0; a < 3; ++a) now_abs = std::max(now_abs, std::max(fabsf(blo[a]), fabsf(bhi[a])));
     sg->max_abs = keep_pad ? std::max(sg->max_abs, now_abs) : now_abs;
     sg->d.pad_abs = kScenePad * sg->max_abs;   // (renderers read sg->d at submission)
-    scene_grid(blo, bhi, sg->d.grid_lo, sg->d.grid_step);
+    // the grid must reach below every PADDED node box: the bounds above are of the bare vertices, and after a refit the kept padding (max_abs never shrinks) may belong
+    // to a place farther from the origin than anything is now — widen by the most a triangle is padded by (padded_box: 4e-6 m + pad_abs + 1e-6 extent) before choosing the grid
+    float glo[3], ghi[3];
+    for (int a = 0; a < 3; ++a) {
+        const float e = 4.0f * sg->d.pad_abs + 2e-6f * (bhi[a] - blo[a]) + 1e-30f;
+        glo[a] = blo[a] - e;
+        ghi[a] = bhi[a] + e;
+    }
+    scene_grid(glo, ghi, sg->d.grid_lo, sg->d.grid_step);
     return LPT_OK;
 }
 

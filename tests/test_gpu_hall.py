@@ -138,3 +138,32 @@ def test_split_triangles_survive_an_instance_edit(device, hall):
     tmax = rng.uniform(0.05, 12.0, n).astype(np.float32)
     assert np.array_equal(sg.trace_occluded(o, d, tmax), osc.trace_occluded(o, d, tmax, brute_force=True))
     fresh.close(); sg.close()
+
+
+def test_a_speck_that_flies_in_from_far_away_keeps_every_hit(device):
+    """round 6: the node origins live on a SCENE GRID (common.h scene_grid) that every refit re-chooses from the triangles' bounds, while the scene-wide part of the
+    triangle padding never shrinks (device.hip scene_bounds_and_grid).  A decimetre of dust 40 000 units from the origin, then moved TO the origin: its padding (from the
+    old place, 0.08) is now wider than the dust itself, and the grid must still reach below every padded node box — the bounds are widened by the padding before the grid is
+    chosen.  Both builders; the moved scene answers like a fresh upload of it and like the oracle's brute force."""
+    from oracle import orc
+    dust = scenes.origin_dust()["dust"]
+    base = scenes.origin_dust()
+    mesh = scenes._mesh(dust.reshape(-1, 3), np.arange(dust.shape[0] * 3, dtype=np.uint32))
+    far = dict(base, meshes=[mesh], instances=[(1, scenes._translate(40000.0, 0.0, 0.0), 1)], triangles=int(dust.shape[0]))
+    near = dict(far, instances=[(1, scenes._translate(0.0, 0.0, 0.0), 1)])
+    osc = orc.OracleScene.from_scene(harness.to_oracle(near), probe=base["probe"])
+    o, d, dist = scenes.grazing_rays(dust, 40000, seed=11, extent=2.0)
+    want = osc.trace_closest(o, d, brute_force=True)
+    assert (want["prim"] != 0xFFFFFFFF).sum() > 10000
+    tmax = (dist * np.random.default_rng(6).uniform(0.5, 1.5, dist.shape[0])).astype(np.float32)
+    want_occ = osc.trace_occluded(o, d, tmax, brute_force=True)
+    for gpu_build in (False, True):
+        scene = scenes.to_product(far)
+        sg = lp.SceneGPU.new_from_scene(scene, device, gpu_build=gpu_build)
+        scene.set_instance_transform(1, scenes._translate(0.0, 0.0, 0.0))     # (instance 0 is the reference's dummy)
+        assert sg.update_instances(scene) == 1
+        got = sg.trace_closest(o, d)
+        for k in ("prim", "t", "u", "v"):
+            assert got[k].tobytes() == want[k].tobytes(), (gpu_build, k, int((got["prim"] != want["prim"]).sum()))
+        assert np.array_equal(sg.trace_occluded(o, d, tmax), want_occ), gpu_build
+        sg.close()
