@@ -320,12 +320,18 @@ def from_profiles_object(avg_launch_ms):
     traffic = traffic_j.get("k_trace_bytes_per_launch")
     binding = None
     if limits_j and "valu_issue" in limits_j and "gather_path" in limits_j:
-        binding = {"name": "vector_memory_path", "frac": limits_j["gather_path"]["frac_of_9.7"], "frac_range": [limits_j["gather_path"]["frac_of_13.5"], limits_j["gather_path"]["frac_of_9.7"]],
-                   "valu_issue_frac": limits_j["valu_issue"]["frac"], "lane_efficiency": (limits_j.get("lane_efficiency") or {}).get("k_trace"),
-                   "note": "the kernel's algorithmic bytes come from L1 / L2 / Infinity Cache, not from the HBM `frac` is quoted against; its launch time follows "
-                           "the bytes a ray pulls through the CU's vector-memory path (measured: fewer or cheaper VALU instructions change nothing, more bytes or "
-                           "fewer cached nodes do — DESIGN 5.1), quoted here against the 9.7-13.5 TB/s a fully divergent dwordx4 gather reaches in the "
-                           "microbenchmark; the VALU issue rate against its own microbenchmark ceiling rides along"}
+        # the limit the kernel sits closest to.  Round 6's clean ceiling probes (profiles/r06_experiments_ab.txt A): +116 VALU instructions per node visit = +14.3 % of
+        # the launch, one more 16-byte load per visit = +9.2 % — the launch follows the VALU issue rate first (0.97-0.98 of the microbenchmark ceiling of its instruction
+        # mix) and the CU's vector-memory path second; both are reported, the larger fraction names the limit
+        vf, gf = limits_j["valu_issue"]["frac"], limits_j["gather_path"]["frac_of_9.7"]
+        binding = {"name": "valu_issue" if vf >= gf else "vector_memory_path", "frac": max(vf, gf),
+                   "valu_issue_frac": vf, "vector_memory_path_frac_range": [limits_j["gather_path"]["frac_of_13.5"], gf],
+                   "lane_efficiency": (limits_j.get("lane_efficiency") or {}).get("k_trace"),
+                   "note": "the kernel's algorithmic bytes come from L1 / L2 / Infinity Cache, not from the HBM `frac` is quoted against.  Its launch time follows the VALU "
+                           "instructions of a node visit (243 per visit, 0.12 % of the launch each: measured with clean A/B probes in round 6, DESIGN 5.1) issued at the "
+                           "ceiling of their mix of full-rate and half-rate instructions (tools/microbench/f16_rate.hip), and second the 16-byte loads a visit pulls through "
+                           "the CU's vector-memory path, quoted against the 9.7-13.5 TB/s a fully divergent dwordx4 gather reaches in the microbenchmark; at a lane "
+                           "efficiency of 0.6 (divergence: SQ_THREAD_CYCLES_VALU / 64 SQ_INSTS_VALU)"}
     here = kernel_source_hash()
     measured_on = (limits_j or {}).get("kernel_source_hash") or traffic_j.get("kernel_source_hash")
     obj = {"what": "replayed from committed rocprofv3 --pmc summaries of an earlier run of this command — NOT measured in this run",

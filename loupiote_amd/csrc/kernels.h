@@ -100,6 +100,7 @@ struct DNoise { const uint8_t *rgba; uint32_t w, h, enabled; };
 struct Queue { float4 *o; float4 *d; float4 *T; };
 struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w = pixel slot bits, c = contribution
 
+constexpr uint32_t kTailCounters = 64u;
 struct FrameCounters {
     // Queue sizes.  The shadow-ray count of bounce b and the closest-hit count of bounce b + 1 — the two queues ONE shading pass fills — sit side by
     // side (qs[2b], qs[2b + 1]), so that a block reserves its slots in both with ONE 64-bit atomic (block_compact2) instead of two round trips;
@@ -128,7 +129,9 @@ struct FrameCounters {
     // power of two (bucket k: 2^k <= steps < 2^(k+1), k = 0..11)
     uint32_t max_steps;
     uint32_t step_hist[12];
-    uint32_t tail_rays;   // rays the waves of k_trace<.., TAIL> finished cooperatively, in place (one atomic per wave that got there)
+    // rays the waves of k_trace<.., TAIL> finished cooperatively, in place: one atomic per wave that got there, spread over kTailCounters words on lines of their own — every
+    // wave of a launch gets there within a few microseconds, and 6 000 atomics on ONE word (~88 per us) held each launch's end back by ~30 us (profiles/r06_experiments_ab.txt I)
+    uint32_t tail_rays[kTailCounters * 32];
 };
 __device__ __host__ __forceinline__ uint32_t &QC(FrameCounters *c, int b) { return b == 0 ? c->q0 : c->qs[2 * (b - 1) + 1]; }
 __device__ __host__ __forceinline__ uint32_t &SC(FrameCounters *c, int b) { return c->qs[2 * b]; }
@@ -707,15 +710,17 @@ __device__ __forceinline__ void coop_merge(Hit &best, const bool cand, const flo
 template <bool STATS>
 __device__ __forceinline__ void coop_walk(const DScene &sc, const f3 o, const f3 d, const float ix, const float iy, const float iz, const bool shadow, Hit &best,
                                           uint32_t *stk, uint32_t count, const uint32_t cap, const uint32_t lane, uint32_t &n_nodes, uint32_t &n_tris) {
-    const uint32_t grp = lane >> 3, c = lane & 7u;
     const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+    // NEAREST ON TOP: lane j of a group tests the child the ray enters j-th LAST (slot = j ^ oinv, the visit order of the lane-per-ray steps: node_fetch pops the highest bit),
+    // and the group with the round's top node is the last one — so the pushes (lane order) leave the nearest child of the nearest node on top of the column
+    const uint32_t grp = lane >> 3, c = (lane & 7u) ^ (7u - ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u)));
     bool done = false;
     while (count && !done) {
         const uint32_t room = count < cap ? cap - count : 0u;
         const uint32_t m = min(min(count, 8u), max(room / 7u, 1u));
         const bool work = grp < m;
         uint32_t node = 0u;
-        if (work) node = stk[count - 1u - grp];
+        if (work) node = stk[count - m + grp];
         __syncthreads();            // every pop is read before the pushes below overwrite the slots
         count -= m;
         bool hit_inner = false, hit_leaf = false;
@@ -1004,7 +1009,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(TAI
         }
     }
     if (TAIL && tail_live) {
-        if (lane == 0) atomicAdd(&ctr->tail_rays, tail_live);
+        if (lane == 0) atomicAdd(&ctr->tail_rays[(blockIdx.x % kTailCounters) * 32u], tail_live);
         tail_walk(sc, tail_live, hits, sq.c, Lsum);
     }
     if (STATS) {
@@ -2102,7 +2107,8 @@ __global__ __launch_bounds__(64) void k_finish_frame(FrameCounters *ctr, Totals 
     tot->shadow_nodes += ctr->shadow_nodes; tot->shadow_tris += ctr->shadow_tris;
     tot->wave_steps += ctr->wave_steps; tot->live_lanes += ctr->live_lanes; tot->node_lanes += ctr->node_lanes; tot->tri_lanes += ctr->tri_lanes;
     tot->shadow_occluded += ctr->shadow_occluded; tot->occ_found += ctr->occ_found; tot->occ_hits += ctr->occ_hits;
-    unsigned long long wr = ctr->tail_rays;
+    unsigned long long wr = 0ull;
+    for (uint32_t k = 0; k < kTailCounters; ++k) wr += ctr->tail_rays[k * 32u];
     for (uint32_t l = 0; l <= bounces && l <= (uint32_t)kMaxBounces; ++l) wr += ctr->strag_count[l];
     tot->wave_rays += wr;
 }

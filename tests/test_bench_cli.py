@@ -93,7 +93,7 @@ def test_replayed_profile_figures_live_under_one_key_and_frac_fabric_rides_with_
     assert obj["kernel_source_hash"]["this_tree"] == bench.kernel_source_hash() and len(obj["kernel_source_hash"]["this_tree"]) == 16
     assert obj["stale"] is (obj["kernel_source_hash"]["profiles"] != obj["kernel_source_hash"]["this_tree"])
     assert traffic == obj["traffic"] and traffic > 1e9 and obj["source"]["traffic"].startswith("profiles/traffic.json")
-    assert obj["binding_limit"]["name"] == "vector_memory_path" and 0 < obj["binding_limit"]["frac"] < 1
+    assert obj["binding_limit"]["name"] in ("valu_issue", "vector_memory_path") and 0 < obj["binding_limit"]["frac"] < 1
     frac, frac_fabric = bench.roofline_fractions(7990.0, traffic, 1.008)
     assert abs(frac - 7990.0 / 8000.0) < 1e-12
     assert abs(frac_fabric - traffic / 1.008e-3 / 1e9 / 8000.0) < 1e-12 and 0.2 < frac_fabric < 0.6
