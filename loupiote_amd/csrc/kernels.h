@@ -103,7 +103,7 @@ struct ShadowQueue { float4 *o; float4 *d; float4 *c; };    // o.w = tmax, d.w =
 constexpr uint32_t kTailCounters = 64u;
 struct FrameCounters {
     // Queue sizes.  The shadow-ray count of bounce b and the closest-hit count of bounce b + 1 — the two queues ONE shading pass fills — sit side by
-    // side (qs[2b], qs[2b + 1]), so that a block reserves its slots in both with ONE 64-bit atomic (block_compact2) instead of two round trips;
+    // side (qs[2b], qs[2b + 1]), so that a block reserves its slots in both with ONE 64-bit atomic (k_shade's default path) instead of two round trips;
     // the primary rays' count has a word of its own.  Accessors: QC (closest-hit rays of bounce b), SC (shadow rays emitted by bounce b).
     uint32_t q0, q0_pad;
     uint32_t qs[2 * kMaxBounces];
@@ -255,32 +255,6 @@ __device__ __forceinline__ uint32_t block_compact(bool valid, uint32_t *counter,
     const uint32_t idx = lds[4 + wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads();  // lds is reused by the next call
     return idx;
-}
-
-// Two compactions with ONE global atomic: a block's slots in the shadow queue (valid_a, the low word of *pair) and in the next-bounce queue
-// (valid_b, the high word) are reserved together — one round trip to the L2 atomic unit and three barriers per block and iteration instead of
-// two and six (k_shade spends its time waiting: round 4).  Must be called by every thread of the block.  `lds` needs 12 uint32.
-__device__ __forceinline__ void block_compact2(bool valid_a, bool valid_b, unsigned long long *pair, uint32_t *lds, uint32_t &idx_a, uint32_t &idx_b) {
-    const unsigned long long ma = __ballot(valid_a), mb = __ballot(valid_b);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) lds[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t c0 = lds[0], c1 = lds[1], c2 = lds[2], c3 = lds[3];
-        const uint32_t a0 = c0 & 0xFFFFu, a1 = c1 & 0xFFFFu, a2 = c2 & 0xFFFFu, a3 = c3 & 0xFFFFu;
-        const uint32_t b0 = c0 >> 16, b1 = c1 >> 16, b2 = c2 >> 16, b3 = c3 >> 16;
-        const uint32_t ta = a0 + a1 + a2 + a3, tb = b0 + b1 + b2 + b3;
-        unsigned long long base = 0ull;
-        if (ta | tb) base = atomicAdd(pair, (unsigned long long)ta | ((unsigned long long)tb << 32));
-        const uint32_t ba = (uint32_t)base, bb = (uint32_t)(base >> 32);
-        lds[4] = ba; lds[5] = ba + a0; lds[6] = ba + a0 + a1; lds[7] = ba + a0 + a1 + a2;
-        lds[8] = bb; lds[9] = bb + b0; lds[10] = bb + b0 + b1; lds[11] = bb + b0 + b1 + b2;
-    }
-    __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    idx_a = lds[4 + wave] + (uint32_t)__popcll(ma & lt);
-    idx_b = lds[8 + wave] + (uint32_t)__popcll(mb & lt);
-    __syncthreads();  // lds is reused by the next call
 }
 
 // Sorted variant of block_compact (the "sorted shade / next-event stage" of the north star): the block's valid
@@ -1624,13 +1598,21 @@ __device__ __forceinline__ void shade_hit(const DScene &sc, const DProbe &probe,
 }
 
 template <bool GBUF>
-__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_shade(DScene sc, DProbe probe, DNoise nz, FrameParams p, Queue qin, const float4 *hits,
                                                   Queue qout, ShadowQueue sq, float4 *Lsum, FrameCounters *ctr, int bounce,
                                                   uint32_t seed_base, GBufArgs gb, int sorted) {
     __shared__ uint32_t lds[72];
     __shared__ float s_lut[256];
+    // ONE RESERVATION FOR TWO ITERATIONS (round 6, log N).  A block reserves its slots in both outgoing queues with one returning atomic — on ONE word for the whole grid:
+    // 32 000 of them in the first launch of a frame, at the ~88 a word sustains per microsecond that alone is 370 us of a 431 us launch (328 us with the atomic taken out,
+    // 308 without any compaction).  So every other iteration only PARKS what it would have stored — a thread's six 16-byte rows and its index within its wave's batch, in
+    // its own LDS slot; no barrier, no atomic — and the iteration behind it reserves for both: half the atomics, three barriers per two iterations.  Which slots a ray
+    // gets is whatever the atomics' order gives, as before; results are keyed by pixel slot.
+    __shared__ float4 s_park[6 * kBlock];
+    __shared__ uint32_t s_at[2 * kBlock];
     s_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];  // kBlock == 256
     __syncthreads();
+    bool parked = false;                   // block-uniform: the previous iteration's rows are waiting in s_park (its per-wave counts in lds[16..19])
     const uint32_t count = QC(ctr, bounce);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounded = (count + 255u) & ~255u;  // keep whole blocks in the loop for the barriers
@@ -1653,11 +1635,51 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, DProbe probe, DNois
                             }, so);
         }
         // `sorted` (wave-uniform; bit 0: next-bounce queue, bit 1: shadow queue): the queue leaves the block ordered by direction octant
-        if (!(sorted & 3)) {   // the default: both queues' slots with one atomic (the last bounce emits no next ray: its word gets + 0)
-            uint32_t si, ni;
-            block_compact2(so.want_shadow, so.want_next && !last_bounce, reinterpret_cast<unsigned long long *>(&SC(ctr, bounce)), lds, si, ni);
-            if (so.want_shadow) { st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
-            if (!last_bounce && so.want_next) { st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
+        if (!(sorted & 3)) {   // the default: both queues' slots with one atomic (the last bounce emits no next ray: its word gets + 0) per TWO iterations
+            const bool va = so.want_shadow, vb = so.want_next && !last_bounce;
+            const unsigned long long ma = __ballot(va), mb = __ballot(vb);
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const uint32_t wa = (uint32_t)__popcll(ma & lt), wb = (uint32_t)__popcll(mb & lt);     // the lane's place in its wave's batch
+            if (!parked && i0 + stride < rounded) {   // park; the next iteration reserves for both
+                if (lane == 0) lds[16 + wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+                s_at[threadIdx.x] = va ? wa : 0xFFFFFFFFu;
+                s_at[kBlock + threadIdx.x] = vb ? wb : 0xFFFFFFFFu;
+                if (va) { s_park[threadIdx.x] = so.so4; s_park[kBlock + threadIdx.x] = so.sd4; s_park[2 * kBlock + threadIdx.x] = so.sc4; }
+                if (vb) { s_park[3 * kBlock + threadIdx.x] = so.no4; s_park[4 * kBlock + threadIdx.x] = so.nd4; s_park[5 * kBlock + threadIdx.x] = so.nT4; }
+                parked = true;
+            } else {
+                if (lane == 0) lds[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    // the block's reservation: [parked wave 0 .. 3][this iteration's wave 0 .. 3], in either queue
+                    uint32_t ra = 0u, rb = 0u;
+                    for (uint32_t w = 0; w < 8u; ++w) {
+                        const uint32_t c = w < 4u ? (parked ? lds[16 + w] : 0u) : lds[w - 4u];
+                        lds[24 + w] = ra; lds[32 + w] = rb;
+                        ra += c & 0xFFFFu; rb += c >> 16;
+                    }
+                    unsigned long long base = 0ull;
+                    if (ra | rb) base = atomicAdd(reinterpret_cast<unsigned long long *>(&SC(ctr, bounce)), (unsigned long long)ra | ((unsigned long long)rb << 32));
+                    lds[40] = (uint32_t)base; lds[41] = (uint32_t)(base >> 32);
+                }
+                __syncthreads();
+                if (parked) {
+                    const uint32_t pa = s_at[threadIdx.x], pb = s_at[kBlock + threadIdx.x];
+                    if (pa != 0xFFFFFFFFu) {
+                        const uint32_t si = lds[40] + lds[24 + wave] + pa;
+                        st_nt(sq.o + si, s_park[threadIdx.x]); st_nt(sq.d + si, s_park[kBlock + threadIdx.x]); st_nt(sq.c + si, s_park[2 * kBlock + threadIdx.x]);
+                    }
+                    if (pb != 0xFFFFFFFFu) {
+                        const uint32_t ni = lds[41] + lds[32 + wave] + pb;
+                        st_nt(qout.o + ni, s_park[3 * kBlock + threadIdx.x]); st_nt(qout.d + ni, s_park[4 * kBlock + threadIdx.x]); st_nt(qout.T + ni, s_park[5 * kBlock + threadIdx.x]);
+                    }
+                }
+                if (va) { const uint32_t si = lds[40] + lds[28 + wave] + wa; st_nt(sq.o + si, so.so4); st_nt(sq.d + si, so.sd4); st_nt(sq.c + si, so.sc4); }
+                if (vb) { const uint32_t ni = lds[41] + lds[36 + wave] + wb; st_nt(qout.o + ni, so.no4); st_nt(qout.d + ni, so.nd4); st_nt(qout.T + ni, so.nT4); }
+                __syncthreads();  // lds is reused by the next reservation
+                parked = false;
+            }
         } else {
             const uint32_t si = (sorted & 2) ? block_compact_binned(so.want_shadow, so.want_shadow ? dir_octant(so.sd4.x, so.sd4.y, so.sd4.z) : 0u, &SC(ctr, bounce), lds)
                                        : block_compact(so.want_shadow, &SC(ctr, bounce), lds);
