@@ -572,7 +572,7 @@ typedef enum lpt_experiment {
     LPT_EXP_PIPE_RAYS = 0,          /* wavefronts of at most this many rays trace with the one-round-trip step (default: all); 0: never */
     LPT_EXP_REFILL = 1,             /* per-bounce traversal: lanes live below which a wave refills (default 44) */
     LPT_EXP_TRACE_WAVES_PER_CU = 2, /* per-bounce traversal: persistent waves per CU; 0 (default): sized from the ray count */
-    LPT_EXP_SHADE_BLOCKS_PER_CU = 3,/* shading pass: blocks per CU (default 4) */
+    LPT_EXP_SHADE_BLOCKS_PER_CU = 3,/* shading pass: blocks per CU; 0 (default) = 4 for a wavefront alone on the chip, 3 for the pieces of a cut batch */
     LPT_EXP_PATH_WAVES_PER_CU = 4,  /* path kernel: persistent waves per CU (default 16) */
     LPT_EXP_PATH_REFILL = 5,        /* path kernel: lanes tracing below which a batch of lanes is shaded / restarted (default 32) */
     LPT_EXP_OCC_CELL_MILLI = 6,     /* stats only: grid cell of the occluder-cache probe in 1/1000 scene units (default 250; 0: probe off) */

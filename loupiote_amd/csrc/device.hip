@@ -224,7 +224,10 @@ struct lpt_renderer {
     // traversal tuning (lpt_renderer_set_option, for experiments)
     int refill = 44;
     int sort_queues = 0;       // k_shade emits both ray queues ordered by direction octant within a block (lpt_renderer_set_sort_queues)
-    uint32_t shade_blocks_per_cu = 4;  // k_shade grid = what is resident at 4 waves/SIMD (LPT_EXP_SHADE_BLOCKS_PER_CU); 8: a 1/8 shard 1.89 instead of 1.80 ms
+    // k_shade grid, blocks per CU (LPT_EXP_SHADE_BLOCKS_PER_CU); 0 = by the submission: 4 (what is resident at 4 waves / SIMD; 8: a 1/8 shard 1.89 instead of 1.80 ms) for a
+    // wavefront that has the chip to itself, 3 for the pieces of a cut batch — three 128-VGPR shading waves leave a SIMD room for one 72-VGPR k_trace wave of the piece on the
+    // other lane: the kernel alone is 10 % slower (2.75 -> 3.05 ms per frame), the frame 0.5 % faster (11.27-11.29 -> 11.19-11.24; profiles/r06_experiments_ab.txt O)
+    uint32_t shade_blocks_per_cu = 0;
     uint32_t trace_waves_per_cu = 0;  // 0 = sized from the frame's ray count (below); LPT_EXP_TRACE_WAVES_PER_CU pins it
     // device memory
     uint32_t n_slots = 0;
@@ -1470,7 +1473,7 @@ int lpt_renderer_set_option(lpt_renderer *r, int option, uint64_t value) {
     case LPT_OPT_WAVEFRONT_RAYS: r->wavefront_rays = std::max<uint64_t>(value, 64u); break;
     case LPT_OPT_EXPERIMENT(LPT_EXP_REFILL): if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_REFILL: 0..63"); r->refill = (int)value; break;
     case LPT_OPT_EXPERIMENT(LPT_EXP_TRACE_WAVES_PER_CU): if (value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_TRACE_WAVES_PER_CU: 0 (auto) or 1..32"); r->trace_waves_per_cu = (uint32_t)value; break;
-    case LPT_OPT_EXPERIMENT(LPT_EXP_SHADE_BLOCKS_PER_CU): if (value < 1u || value > 64u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_SHADE_BLOCKS_PER_CU: 1..64"); r->shade_blocks_per_cu = (uint32_t)value; break;
+    case LPT_OPT_EXPERIMENT(LPT_EXP_SHADE_BLOCKS_PER_CU): if (value > 64u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_SHADE_BLOCKS_PER_CU: 0 (by the submission) or 1..64"); r->shade_blocks_per_cu = (uint32_t)value; break;
     case LPT_OPT_PATH_RAYS: r->path_rays = (uint32_t)std::min<uint64_t>(value, 0x7FFFFFFFu); break;
     case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_WAVES_PER_CU): if (value < 1u || value > 32u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_PATH_WAVES_PER_CU: 1..32"); r->path_waves_per_cu = (uint32_t)value; break;
     case LPT_OPT_EXPERIMENT(LPT_EXP_PATH_REFILL): if (value > 63u) return fail(LPT_ERR_INVALID_ARG, "LPT_EXP_PATH_REFILL: 0..63"); r->path_refill = (int)value; break;
@@ -1705,7 +1708,7 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
         HIP_TRY(hipMemsetAsync(wf.ctr, 0, sizeof(FrameCounters), s));
         const uint32_t cus = (uint32_t)r->dev->compute_units;
         const uint32_t stream_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * 8u);
-        const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * r->shade_blocks_per_cu);
+        const uint32_t shade_blocks = std::min<uint32_t>(div_up(n_rays, kBlock), cus * (r->shade_blocks_per_cu ? r->shade_blocks_per_cu : (solo ? 4u : 3u)));
         // the one-round-trip step (kernels.h ray_step_pipe): 72 VGPRs (round 6; 78 before), 6 waves per SIMD used of the 7 that fit, ~3 % more nodes and ~12 % more
         // triangles fetched per ray — and still 1 % less time per frame at 8 M rays, 2 % for a 1 M-ray tile shard
         // (profiles/r03_experiments_ab.txt); LPT_EXP_PIPE_RAYS 0 selects the two-round-trip step
