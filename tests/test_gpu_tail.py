@@ -156,3 +156,18 @@ def test_tail_on_the_trees_of_the_gpu_builder(device):
         for key, got in frames.items():
             assert got[1] == ref[1] and got[0].tobytes() == ref[0].tobytes(), (desc["name"], key)
         pr.close()
+
+
+@pytest.mark.parametrize("size,spp", [((64, 64), 1), ((203, 117), 4), ((256, 136), 3), ((320, 200), 4)])
+def test_shading_grids_of_every_shape_park_and_reserve_to_the_same_frame(device, cornell, cornell_glb, size, spp):
+    """round 6: k_shade reserves queue slots once per TWO iterations — every other iteration only parks its rows in LDS (kernels.h k_shade).  Small grids
+    (LPT_EXP_SHADE_BLOCKS_PER_CU 1 / 2 / 3: 256 .. 768 blocks) make the blocks of these frames loop 1 .. 5 times, some of them once more than others: a lone iteration
+    (nothing parked), park + reserve, and a last iteration that reserves alone behind a pair — each shape must give the oracle's frame and ray counts."""
+    _, sg, pr = cornell
+    view = T.look(T.CORNELL_EYE, T.CORNELL_DIR)
+    ref, oc = harness.render_oracle(cornell_glb, size[0], size[1], 5, spp)
+    for blocks in (0, 1, 2, 3):
+        for extra in ({}, {"wavefront_rays": 40000}):      # (and the same frame cut into pieces: grids of 3 blocks per CU by default)
+            img, counts = _render(device, sg, pr, size, 5, spp, dict(PER_BOUNCE, shade_blocks_per_cu=blocks, **extra), view)
+            assert counts == (oc.closest, oc.shadow, oc.shaded), (blocks, extra)
+            assert img.tobytes() == ref.tobytes(), (blocks, extra)
