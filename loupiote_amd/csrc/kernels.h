@@ -449,14 +449,14 @@ __device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const
         const float tbest = rs.best.t;
         uint32_t h = 0u;   // bit s: the ray's interval meets slot s's box
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 1; half >= 0; --half) {   // slot 7 first: every test shifts the bits found so far up and adds its own (one add with carry per child)
             const uint32_t lox = half ? n2.y : n2.x, loy = half ? n2.w : n2.z, loz = half ? n3.y : n3.x;
             const uint32_t hix = half ? n3.w : n3.z, hiy = half ? n4.y : n4.x, hiz = half ? n4.w : n4.z;
             const uint32_t qnx = negx ? hix : lox, qfx = negx ? lox : hix;
             const uint32_t qny = negy ? hiy : loy, qfy = negy ? loy : hiy;
             const uint32_t qnz = negz ? hiz : loz, qfz = negz ? loz : hiz;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 3; j >= 0; --j) {
                 const int sh = 8 * j;
                 const float tnx = fmaf((float)((qnx >> sh) & 0xFFu), ax, bnx);
                 const float tny = fmaf((float)((qny >> sh) & 0xFFu), ay, bny);
@@ -466,7 +466,8 @@ __device__ __forceinline__ uint2 node_test(const DScene &sc, RayState &rs, const
                 const float tfz = fmaf((float)((qfz >> sh) & 0xFFu), az, bfz);
                 const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
                 const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tbest));
-                if (tn <= tf) h |= 1u << (4 * half + j);
+                // h = 2 h + (tn <= tf): the compare's lane mask goes in as the carry of ONE add (the compiler's own form is a v_cndmask per child and a v_or3 per two)
+                asm("v_cmp_le_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(tn), "v"(tf) : "vcc");
             }
         }
         // empty slots have inverted boxes; should the widening ever let one pass, it is in neither mask below
