@@ -66,7 +66,21 @@ constexpr int ITER = 4096;
     F(50, "v_pk_mul_lo_u16", "v_pk_mul_lo_u16 %0, %0, %2") \
     F(51, "v_mul_u32_u24", "v_mul_u32_u24_e32 %0, %2, %0") \
     F(52, "v_fma_mix_f32 (f16 b)", "v_fma_mix_f32 %0, %0, %2, %3 op_sel_hi:[0,1,0]") \
-    F(53, "v_mad_u32_u24", "v_mad_u32_u24 %0, %0, %2, %3")
+    F(53, "v_mad_u32_u24", "v_mad_u32_u24 %0, %0, %2, %3") \
+    F(54, "v_mov_b32_sdwa byte->byte1 preserve", "v_mov_b32_sdwa %0, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2") \
+    F(55, "v_or_b32_sdwa src byte", "v_or_b32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2") \
+    F(56, "v_mov_b32_sdwa byte->dword", "v_mov_b32_sdwa %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2") \
+    F(57, "v_addc_co_u32", "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc") \
+    F(58, "v_alignbit_b32", "v_alignbit_b32 %0, %0, %2, 31") \
+    F(59, "v_cmp_le_f32 vcc", "v_cmp_le_f32_e32 vcc, %0, %2") \
+    F(60, "v_min3_f32", "v_min3_f32 %0, %0, %2, %3") \
+    F(61, "v_add_f32", "v_add_f32_e32 %0, %2, %0") \
+    F(62, "v_mul_f32", "v_mul_f32_e32 %0, %2, %0") \
+    F(63, "v_fmac_f32 (VOP2)", "v_fmac_f32_e32 %0, %2, %3") \
+    F(64, "v_fma_f32 clamp", "v_fma_f32 %0, %0, %2, %3 clamp") \
+    F(65, "v_max3_f32", "v_max3_f32 %0, %0, %2, %3") \
+    F(66, "v_med3_f32", "v_med3_f32 %0, %0, %2, %3") \
+    F(67, "v_cmp_lt_f32 vcc", "v_cmp_lt_f32_e32 vcc, %0, %2")
 
 template <int OP>
 __global__ __launch_bounds__(64) void k(uint32_t *out, uint32_t a, uint32_t b, unsigned long long *cyc) {
