@@ -1767,13 +1767,13 @@ static int wavefront_trace(lpt_renderer *r, const float view[16], uint32_t n_sam
                 return;
             }
             if (tail) {
-                if (pipe) hipLaunchKernelGGL((k_trace<false, true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
-                else hipLaunchKernelGGL((k_trace<false, false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail);
+                if (pipe) hipLaunchKernelGGL((k_trace<false, true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail});
+                else hipLaunchKernelGGL((k_trace<false, false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + tail_lds, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, 0u, wf.strag, launch_no, tail});
             } else if (pipe) {
-                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
-                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
-            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u);
+                if (r->stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u});
+                else hipLaunchKernelGGL((k_trace<false, true>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u});
+            } else if (r->stats) hipLaunchKernelGGL((k_trace<true, false>), dim3(trace_blocks), dim3(kTraceBlock), lds + 64u, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u});
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(trace_blocks), dim3(kTraceBlock), lds, s, TraceKernargs{sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, r->refill, occ, budget, wf.strag, launch_no, 0u});
             if (budget) {   // the launch's stragglers, a whole wave each (most waves of this grid find none and leave at once)
                 const size_t clds = sizeof(uint32_t) * coop_stack_entries(kCoopStack, r->sg->stats.max_depth);
                 if (r->stats) hipLaunchKernelGGL(k_trace_coop<true>, dim3(cus * kCoopWavesPerCu), dim3(kTraceBlock), clds, s, sc, qin, wf.hits, wf.sq, wf.Lsum, wf.ctr, cb, sb, wf.strag, launch_no);
